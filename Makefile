@@ -1,0 +1,64 @@
+# Top-level build.  Default target mirrors the reference's Makefile target name (nbody-sim-new/Makefile:7):
+#   make            -> libnbody_hip.so (HIP, gfx950) + oracle + nbody_sim harness
+#   make lib        -> nbody-simulation-parallel_amd/libnbody_hip.so only
+PKG      := nbody-simulation-parallel_amd
+CSRC     := $(PKG)/csrc
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+LIB      := $(PKG)/libnbody_hip.so
+
+# host side: the reference's own flags (nbody-sim-new/Makefile:1-3)
+CXX      ?= g++
+CXXFLAGS := -std=c++17 -O3 -fopenmp -Iinclude -I$(PKG)/host
+LDFLAGS  := -fopenmp
+
+all: lib oracle nbody_sim
+
+lib: $(LIB)
+
+OBJS := $(CSRC)/force_kernel_slp.o $(CSRC)/force_kernel_scalar.o $(CSRC)/force_launch.o \
+        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o
+# name of the force-kernel variant used when the caller does not pick one
+DEFAULT_VARIANT ?= lds_t1_w8_exact_u8_scalar
+
+# the force kernel is built in two code-generation flavours (see force_kernel.hip)
+$(CSRC)/force_kernel_slp.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=slp -c $< -o $@
+
+$(CSRC)/force_kernel_scalar.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=scalar -fno-slp-vectorize -c $< -o $@
+
+$(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -c $< -o $@
+
+# -ffp-contract=off: the fp64 kick/drift must round like the reference's two-step arithmetic
+$(CSRC)/state_kernels.o: $(CSRC)/state_kernels.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+
+$(CSRC)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.h include/nbody_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+HOST_SRCS := $(wildcard $(PKG)/host/*.cpp)
+nbody_sim: $(LIB) $(HOST_SRCS)
+	@if [ -n "$(HOST_SRCS)" ]; then \
+	  $(CXX) $(CXXFLAGS) $(HOST_SRCS) -o $@ $(LDFLAGS) -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/$(PKG)'; \
+	else echo "host harness not built yet"; fi
+
+tools/bench_force: tools/bench_force.cpp $(LIB)
+	$(CXX) -std=c++17 -O2 -Iinclude $< -o $@ -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
+tools/ubench_valu: tools/ubench_valu.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
+
+clean:
+	rm -f $(OBJS) $(LIB) nbody_sim tools/bench_force tools/ubench_valu
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

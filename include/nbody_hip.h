@@ -1,0 +1,151 @@
+/*
+ * nbody_hip.h -- C ABI of libnbody_hip.so: the MI355X (gfx950) all-pairs force + kick/drift path.
+ *
+ * This is the drop-in boundary for ONE hot path of mathaiml5/NBody-simulation-parallel: the O(N^2)
+ * brute-force force evaluation and the two integrator helpers.  The reference has no FFI; its
+ * "plugin API" is the free-function template shape of nbody-sim-new/methods.h:29-37 and :85-91,
+ * called from run_benchmark<D> (nbody-sim-new/main.cpp:137-140).  Every entry point below names the
+ * reference interface it replaces.  C++ wrappers with the reference's exact signatures live in
+ * nbody-simulation-parallel_amd/host/methods_hip.h; INTEGRATION.md shows the harness-side binding.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, opaque context handle, int status (0 = NBX_OK).
+ *    No C++ types, no exceptions, no torch types cross this boundary.
+ *  - Host body arrays are the reference's Body<D> memory (nbody-sim-new/body.h:8-11):
+ *    double position[D]; double velocity[D]; double mass;  i.e. stride 56 B (D=3) / 40 B (D=2).
+ *    Host force arrays are the reference's Vector<D> memory (vector.h:9-12): double[D] per body.
+ *  - The device computes in fp32 on SoA arrays; positions and masses are rounded to fp32 at this
+ *    boundary.  Returned forces are F_i = -(G m_i) * sum_j m_j (p_j - p_i)/r^4 with pairs of
+ *    r^2 < 1e-10 skipped -- the reference law exactly as written (methods.cpp:21-37), including its
+ *    sign and its extra power of r; G*m_i is applied in fp64.
+ *  - There is NO CPU fallback: without a usable HIP device every compute call fails with
+ *    NBX_ERR_NO_DEVICE / NBX_ERR_HIP.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBX_ABI_VERSION 1
+
+/* status codes */
+enum {
+    NBX_OK = 0,
+    NBX_ERR_INVALID = 1,    /* bad argument (null pointer, dim not 2/3, shard out of range ...) */
+    NBX_ERR_NO_DEVICE = 2,  /* no HIP device visible */
+    NBX_ERR_HIP = 3,        /* a HIP runtime call failed; nbx_last_error_detail() has the text */
+    NBX_ERR_ALLOC = 4,      /* device or host allocation failed */
+    NBX_ERR_STATE = 5       /* call made in the wrong order (e.g. step before upload) */
+};
+
+/* nbody-sim-new/utils.h:21 -- the reference's G, for callers that do not carry their own. */
+#define NBX_REFERENCE_G 4.471e-21
+/* nbody-sim-new/methods.cpp:24 -- pairs with r^2 below this are skipped. */
+#define NBX_R2_SKIP 1e-10
+
+typedef struct nbx_ctx nbx_ctx;
+
+/* ---- library --------------------------------------------------------------------------------- */
+int nbx_abi_version(void);
+const char* nbx_strerror(int status);
+/* Text of the last HIP failure seen by the calling thread ("" if none). */
+const char* nbx_last_error_detail(void);
+int nbx_device_count(int* count);
+
+/* ---- one-shot entry points (host memory in, host memory out) --------------------------------- */
+
+/* Replaces brute_force_seq_n_body<D> / brute_force_omp_n_body_{1,2}<D>
+ * (nbody-sim-new/methods.h:29-37; methods.cpp:7-42, 45-95, 98-136).
+ * bodies: n x Body<dim>, body_stride_bytes = sizeof(Body<dim>) (56 or 40; larger strides allowed).
+ * forces_out: n x Vector<dim> (n*dim doubles).  Runs pack -> H2D -> kernel -> D2H on `device`.
+ * kernel_ms (optional) receives the force kernel's own duration (hipEvent), for roofline figures;
+ * the wall time of the whole call is what the reference's safely_execute (utils.h:87-104) times. */
+int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
+                           double G, int device, double* forces_out, float* kernel_ms);
+
+/* Replaces the loop  { f = brute_force_*_n_body(bodies); update_body_velocities(bodies, f, dt);
+ * update_body_positions(bodies, dt); }  repeated nsteps times (methods.h:85-91; methods.cpp:425-450;
+ * the reference defines the two helpers but never calls them -- SURVEY F6).  bodies is updated in
+ * place (positions and velocities; masses untouched).  State stays on the device between steps. */
+int nbx_leapfrog(void* bodies, size_t n, int dim, size_t body_stride_bytes,
+                 double G, double dt, int nsteps, int device, float* kernel_ms_total);
+
+/* ---- device-resident context ------------------------------------------------------------------
+ * A context owns the targets of ONE shard of an N-body system on ONE device and a full-length
+ * fp32 copy of all N sources.  n_shards = 1, shard = 0 is the single-GPU case.  With n_shards = G
+ * the bodies are split into G contiguous shards of shard_len = ceil(N/G) bodies (the last one
+ * short); rank g creates a context with shard = g and exchanges fp32 positions with the others
+ * once per step (RCCL all-gather of the buffer described by nbx_ctx_gather_layout).
+ */
+int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_shards, int shard);
+int nbx_ctx_destroy(nbx_ctx* ctx);
+
+/* Use a caller-owned HIP stream (hipStream_t as void*) for every launch and copy of this context;
+ * NULL restores the context's own stream.  Lets a torch.cuda.Stream order the kernels. */
+int nbx_ctx_set_stream(nbx_ctx* ctx, void* hip_stream);
+
+/* Use caller-owned device memory for the two all-gather buffers (see nbx_ctx_gather_layout for the
+ * required sizes).  Must be called before nbx_ctx_upload_bodies.  This is how the one-process-per-
+ * GPU host layer hands torch-allocated tensors to RCCL and to the kernels without a copy. */
+int nbx_ctx_set_gather_buffers(nbx_ctx* ctx, void* pos_all_f32, void* mass_all_f32);
+
+/* Layout of the exchange buffers:
+ *   pos_all : float[n_shards][dim][shard_pad]   -- chunk g = shard g's x[], y[], (z[]) arrays
+ *   mass_all: float[n_shards][shard_pad]
+ * shard_len = bodies per shard, shard_pad = shard_len rounded up to the source tile (256); pad
+ * entries are massless bodies at the origin (they contribute exactly zero).
+ * Any out pointer may be NULL. */
+int nbx_ctx_gather_layout(const nbx_ctx* ctx, size_t* shard_len, size_t* shard_pad,
+                          void** pos_all_f32, void** mass_all_f32);
+
+/* Upload ALL n_total bodies (Body<dim> array as above).  Fills the fp32 source copy for every
+ * shard and the fp64 position/velocity/mass state of this context's own shard. */
+int nbx_ctx_upload_bodies(nbx_ctx* ctx, const void* bodies, size_t body_stride_bytes);
+
+/* Accelerations of this shard's targets: a_i = sum_j m_j (p_j - p_i)/r^4 over the selected sources
+ * (the reference force without the -(G m_i) factor).  which: 0 = all shards' sources,
+ * 1 = only this shard's own chunk (needs no remote data), 2 = every other shard's chunk, added to
+ * what a preceding which=1 call produced.  Asynchronous on the context's stream. */
+enum { NBX_SRC_ALL = 0, NBX_SRC_LOCAL = 1, NBX_SRC_REMOTE = 2 };
+int nbx_ctx_compute_accel(nbx_ctx* ctx, int which);
+
+/* Fused kick + drift for this shard (methods.cpp:425-438 then :440-450, fp64):
+ *   F = -(G m) a;  v += (F / m) * dt;  x += v * dt;
+ * and refresh of this shard's fp32 chunk of pos_all.  Asynchronous on the context's stream. */
+int nbx_ctx_kick_drift(nbx_ctx* ctx, double G, double dt);
+
+/* nsteps x { compute_accel(ALL); kick_drift } -- single-shard contexts only (n_shards == 1). */
+int nbx_ctx_step(nbx_ctx* ctx, double G, double dt, int nsteps);
+
+/* Forces of this shard's targets as Vector<dim>[shard_len] doubles: F_i = -(G m_i) a_i.
+ * Synchronises the stream. */
+int nbx_ctx_get_forces(nbx_ctx* ctx, double G, double* forces_out);
+/* Raw fp32 accelerations, SoA float[dim][shard_len].  Synchronises the stream. */
+int nbx_ctx_get_accel(nbx_ctx* ctx, float* accel_out);
+/* Write this shard's positions and velocities (fp64 state) back into the caller's full-length
+ * Body<dim> array (only entries [shard*shard_len, ...) are touched).  Synchronises the stream. */
+int nbx_ctx_download_bodies(nbx_ctx* ctx, void* bodies, size_t body_stride_bytes);
+
+int nbx_ctx_synchronize(nbx_ctx* ctx);
+
+/* Tuning knobs.  source_splits: number of slices the source loop is cut into (0 = automatic; more
+ * workgroups for small shards; partial sums are combined in a fixed order).  variant: force-kernel
+ * variant id in [0, nbx_num_variants()), -1 = library default (see DESIGN.md for the table). */
+int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
+int nbx_num_variants(void);
+const char* nbx_variant_name(int variant);
+int nbx_default_variant(void);
+
+/* Mean duration in ms of the force-kernel launches since the last call (hipEvent pairs recorded on
+ * the context's stream around each launch), and how many launches that covers.  Synchronises. */
+int nbx_ctx_kernel_time(nbx_ctx* ctx, float* mean_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

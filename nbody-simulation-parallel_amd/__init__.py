@@ -1,0 +1,14 @@
+"""nbody-simulation-parallel_amd: MI355X-native all-pairs force + kick/drift hot path.
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so import it
+through the root-level shim:  `import nbody_amd as nbx`  (or importlib with the name
+`nbody_simulation_parallel_amd`).  Contents:
+  csrc/      hand-written HIP kernels for gfx950 + the C ABI (include/nbody_hip.h)
+  host/      C++ mirror of the reference's methods.h entry points + benchmark harness
+  capi.py    ctypes binding of the C ABI (same entry-point names for Python callers / tests)
+  sharding.py, dist.py   one-process-per-GPU sharding over torch.distributed (RCCL)
+"""
+from .capi import (  # noqa: F401
+    ABI, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE, Context, NbxError,
+    body_stride, brute_force_hip_n_body, device_count, leapfrog_hip_n_body, load_library, variants,
+)

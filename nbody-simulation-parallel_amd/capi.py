@@ -1,0 +1,232 @@
+"""ctypes binding of libnbody_hip.so (C ABI: include/nbody_hip.h).
+
+Host-side mirror of the reference's solver entry points for the brute-force path
+(nbody-sim-new/methods.h:29-37, :85-91) for Python callers and for the tests: same names,
+same argument meaning (an array of Body<D> in, an array of Vector<D> forces out), same error
+behaviour (a failure raises, like the C++ wrappers throw into the harness's safely_execute,
+utils.h:87-104).  Nothing here computes: every call goes through the C ABI into the HIP library,
+and a missing library or missing GPU raises NbxError -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+NBX_OK = 0
+NBX_ERR_INVALID, NBX_ERR_NO_DEVICE, NBX_ERR_HIP, NBX_ERR_ALLOC, NBX_ERR_STATE = 1, 2, 3, 4, 5
+SRC_ALL, SRC_LOCAL, SRC_REMOTE = 0, 1, 2
+REFERENCE_G = 4.471e-21  # nbody-sim-new/utils.h:21
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libnbody_hip.so")
+
+# every symbol include/nbody_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_vp, _sz, _i, _d = _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_double
+_pf, _pd, _pi = _c.POINTER(_c.c_float), _c.POINTER(_c.c_double), _c.POINTER(_c.c_int)
+ABI = [
+    ("nbx_abi_version", _i, []),
+    ("nbx_strerror", _c.c_char_p, [_i]),
+    ("nbx_last_error_detail", _c.c_char_p, []),
+    ("nbx_device_count", _i, [_pi]),
+    ("nbx_brute_force_forces", _i, [_vp, _sz, _i, _sz, _d, _i, _vp, _pf]),
+    ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
+    ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),
+    ("nbx_ctx_destroy", _i, [_vp]),
+    ("nbx_ctx_set_stream", _i, [_vp, _vp]),
+    ("nbx_ctx_set_gather_buffers", _i, [_vp, _vp, _vp]),
+    ("nbx_ctx_gather_layout", _i, [_vp, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_vp), _c.POINTER(_vp)]),
+    ("nbx_ctx_upload_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_ctx_compute_accel", _i, [_vp, _i]),
+    ("nbx_ctx_kick_drift", _i, [_vp, _d, _d]),
+    ("nbx_ctx_step", _i, [_vp, _d, _d, _i]),
+    ("nbx_ctx_get_forces", _i, [_vp, _d, _vp]),
+    ("nbx_ctx_get_accel", _i, [_vp, _vp]),
+    ("nbx_ctx_download_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_ctx_synchronize", _i, [_vp]),
+    ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
+    ("nbx_num_variants", _i, []),
+    ("nbx_variant_name", _c.c_char_p, [_i]),
+    ("nbx_default_variant", _i, []),
+    ("nbx_ctx_kernel_time", _i, [_vp, _pf, _pi]),
+]
+
+
+class NbxError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: nbx status {status}" + (f" -- {detail}" if detail else ""))
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libnbody_hip.so and type every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NbxError(-1, "load_library", f"{p} not found: build it with `make lib` (hipcc, gfx950); "
+                       "there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, res, args in ABI:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, where: str):
+    if rc != NBX_OK:
+        msg = lib.nbx_strerror(rc).decode()
+        det = lib.nbx_last_error_detail().decode()
+        raise NbxError(rc, where, f"{msg}: {det}" if det else msg)
+
+
+def body_stride(dim: int) -> int:
+    """doubles per Body<dim> (nbody-sim-new/body.h:8-11): position[D], velocity[D], mass."""
+    return 2 * dim + 1
+
+
+def _as_bodies(bodies: np.ndarray, writable: bool = False) -> Tuple[np.ndarray, int]:
+    b = np.asarray(bodies)
+    if b.dtype != np.float64 or b.ndim != 2 or b.shape[1] not in (5, 7):
+        raise ValueError("bodies must be float64 [n, 2*D+1] rows of Body<D> = (position[D], velocity[D], mass)")
+    if not b.flags["C_CONTIGUOUS"] or (writable and not b.flags["WRITEABLE"]):
+        if writable:
+            raise ValueError("bodies must be a writable C-contiguous array")
+        b = np.ascontiguousarray(b)
+    return b, (b.shape[1] - 1) // 2
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = ctypes.c_int(0)
+    _check(lib, lib.nbx_device_count(ctypes.byref(n)), "nbx_device_count")
+    return n.value
+
+
+def variants():
+    lib = load_library()
+    return [lib.nbx_variant_name(i).decode() for i in range(lib.nbx_num_variants())]
+
+
+def brute_force_hip_n_body(bodies: np.ndarray, G: float = REFERENCE_G, device: int = 0,
+                           return_kernel_ms: bool = False):
+    """forces = brute_force_hip_n_body(bodies): drop-in for brute_force_seq_n_body<D> /
+    brute_force_omp_n_body_{1,2}<D> (nbody-sim-new/methods.h:29-37).  bodies: float64 [n, 2D+1];
+    returns float64 [n, D] forces (Vector<D> per body)."""
+    lib = load_library()
+    b, dim = _as_bodies(bodies)
+    n = b.shape[0]
+    out = np.empty((n, dim), dtype=np.float64)
+    ms = ctypes.c_float(0.0)
+    rc = lib.nbx_brute_force_forces(b.ctypes.data, n, dim, b.strides[0], G, device, out.ctypes.data,
+                                    ctypes.byref(ms))
+    _check(lib, rc, "nbx_brute_force_forces")
+    return (out, ms.value) if return_kernel_ms else out
+
+
+def leapfrog_hip_n_body(bodies: np.ndarray, dt: float, nsteps: int, G: float = REFERENCE_G, device: int = 0):
+    """In-place nsteps x { forces; update_body_velocities; update_body_positions }
+    (nbody-sim-new/methods.cpp:425-450), state resident on the device between steps."""
+    lib = load_library()
+    b, dim = _as_bodies(bodies, writable=True)
+    ms = ctypes.c_float(0.0)
+    rc = lib.nbx_leapfrog(b.ctypes.data, b.shape[0], dim, b.strides[0], G, dt, nsteps, device, ctypes.byref(ms))
+    _check(lib, rc, "nbx_leapfrog")
+    return ms.value
+
+
+class Context:
+    """Device-resident shard of an N-body system (nbx_ctx_* of include/nbody_hip.h)."""
+
+    def __init__(self, n_total: int, dim: int = 3, device: int = 0, n_shards: int = 1, shard: int = 0):
+        self.lib = load_library()
+        self.n_total, self.dim, self.device, self.n_shards, self.shard = n_total, dim, device, n_shards, shard
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.nbx_ctx_create(ctypes.byref(h), device, dim, n_total, n_shards, shard),
+               "nbx_ctx_create")
+        self.h = h
+        sl, sp = ctypes.c_size_t(), ctypes.c_size_t()
+        _check(self.lib, self.lib.nbx_ctx_gather_layout(self.h, ctypes.byref(sl), ctypes.byref(sp), None, None),
+               "nbx_ctx_gather_layout")
+        self.shard_len, self.shard_pad = sl.value, sp.value
+        lo = shard * self.shard_len
+        self.count = max(0, min(self.shard_len, n_total - lo))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc, where):
+        _check(self.lib, rc, where)
+
+    def set_stream(self, raw_stream: int):
+        self._ck(self.lib.nbx_ctx_set_stream(self.h, ctypes.c_void_p(raw_stream)), "nbx_ctx_set_stream")
+
+    def set_gather_buffers(self, pos_ptr: int, mass_ptr: int):
+        self._ck(self.lib.nbx_ctx_set_gather_buffers(self.h, ctypes.c_void_p(pos_ptr), ctypes.c_void_p(mass_ptr)),
+                 "nbx_ctx_set_gather_buffers")
+
+    def set_tuning(self, source_splits: int = 0, variant: int = -1):
+        self._ck(self.lib.nbx_ctx_set_tuning(self.h, source_splits, variant), "nbx_ctx_set_tuning")
+
+    def upload(self, bodies: np.ndarray):
+        b, dim = _as_bodies(bodies)
+        if dim != self.dim or b.shape[0] != self.n_total:
+            raise ValueError("bodies shape does not match the context")
+        self._ck(self.lib.nbx_ctx_upload_bodies(self.h, b.ctypes.data, b.strides[0]), "nbx_ctx_upload_bodies")
+
+    def compute_accel(self, which: int = SRC_ALL):
+        self._ck(self.lib.nbx_ctx_compute_accel(self.h, which), "nbx_ctx_compute_accel")
+
+    def kick_drift(self, dt: float, G: float = REFERENCE_G):
+        self._ck(self.lib.nbx_ctx_kick_drift(self.h, G, dt), "nbx_ctx_kick_drift")
+
+    def step(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
+        self._ck(self.lib.nbx_ctx_step(self.h, G, dt, nsteps), "nbx_ctx_step")
+
+    def forces(self, G: float = REFERENCE_G) -> np.ndarray:
+        out = np.empty((self.count, self.dim), dtype=np.float64)
+        self._ck(self.lib.nbx_ctx_get_forces(self.h, G, out.ctypes.data), "nbx_ctx_get_forces")
+        return out
+
+    def accel(self) -> np.ndarray:
+        out = np.empty((self.dim, self.count), dtype=np.float32)
+        self._ck(self.lib.nbx_ctx_get_accel(self.h, out.ctypes.data), "nbx_ctx_get_accel")
+        return out
+
+    def download(self, bodies: np.ndarray):
+        b, dim = _as_bodies(bodies, writable=True)
+        if dim != self.dim or b.shape[0] != self.n_total:
+            raise ValueError("bodies shape does not match the context")
+        self._ck(self.lib.nbx_ctx_download_bodies(self.h, b.ctypes.data, b.strides[0]), "nbx_ctx_download_bodies")
+
+    def synchronize(self):
+        self._ck(self.lib.nbx_ctx_synchronize(self.h), "nbx_ctx_synchronize")
+
+    def kernel_time(self) -> Tuple[float, int]:
+        ms, cnt = ctypes.c_float(0.0), ctypes.c_int(0)
+        self._ck(self.lib.nbx_ctx_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(cnt)), "nbx_ctx_kernel_time")
+        return ms.value, cnt.value

@@ -1,0 +1,428 @@
+// nbx_api.hip -- the C ABI of include/nbody_hip.h: context management, boundary conversions,
+// stream/event plumbing.  No compute happens on the host and there is no CPU fallback: every
+// entry point that needs the device fails loudly when HIP does.
+#include "../../include/nbody_hip.h"
+#include "nbx_internal.h"
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace nbx;
+
+namespace {
+
+thread_local std::string g_detail;
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s failed: %s (%s) at %s:%d", what, hipGetErrorString(e), hipGetErrorName(e), file, line);
+    g_detail = buf;
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? NBX_ERR_NO_DEVICE
+           : (e == hipErrorOutOfMemory)                           ? NBX_ERR_ALLOC
+                                                                  : NBX_ERR_HIP;
+}
+int fail(int code, const char* msg) {
+    g_detail = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kEventPairs = 512;
+
+}  // namespace
+
+struct nbx_ctx {
+    int device = 0, dim = 3, n_shards = 1, shard = 0;
+    size_t n_total = 0, shard_len = 0, count = 0;  // count = real bodies in this shard
+    unsigned pad = 0;
+    int splits = 1, variant = 0;
+    bool splits_user = false;
+    bool uploaded = false, have_accel = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // exchange buffers (own or caller's)
+    float* pos_all = nullptr;
+    float* mass_all = nullptr;
+    bool own_gather = true;
+    // own shard
+    double *x64 = nullptr, *v64 = nullptr, *m64 = nullptr;
+    float* acc = nullptr;
+    int acc_splits_alloc = 0;
+    // boundary staging
+    double* stage = nullptr;
+    size_t stage_bytes = 0;
+    // kernel timing
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_used = 0;
+    int launches_since_query = 0;
+    int num_cus = 256;
+};
+
+namespace {
+
+int ensure_stage(nbx_ctx* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return NBX_OK;
+    if (c->stage) { HIP_TRY(hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
+    HIP_TRY(hipMalloc((void**)&c->stage, bytes));
+    c->stage_bytes = bytes;
+    return NBX_OK;
+}
+
+// Source slices: enough workgroups to give every SIMD >= 2 waves even for a small shard.
+int auto_splits(const nbx_ctx* c, int tpl) {
+    const unsigned tgt_blocks = c->pad / (256u * (unsigned)tpl);
+    const unsigned want_blocks = (unsigned)c->num_cus * 4u;  // 4 workgroups (16 waves) per CU
+    unsigned s = (want_blocks + tgt_blocks - 1) / tgt_blocks;
+    const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
+    const unsigned max_s = tiles / 8 ? tiles / 8 : 1;  // keep >= 8 tiles (2048 sources) per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+
+int ensure_acc(nbx_ctx* c) {
+    if (!c->splits_user) c->splits = auto_splits(c, variant_tpl(c->variant));
+    if (c->acc && c->acc_splits_alloc >= c->splits) return NBX_OK;
+    if (c->acc) { HIP_TRY(hipFree(c->acc)); c->acc = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
+    c->acc_splits_alloc = c->splits;
+    return NBX_OK;
+}
+
+int set_device(const nbx_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_abi_version(void) { return NBX_ABI_VERSION; }
+
+const char* nbx_strerror(int status) {
+    switch (status) {
+        case NBX_OK: return "ok";
+        case NBX_ERR_INVALID: return "invalid argument";
+        case NBX_ERR_NO_DEVICE: return "no usable HIP device (libnbody_hip has no CPU fallback)";
+        case NBX_ERR_HIP: return "HIP runtime error";
+        case NBX_ERR_ALLOC: return "allocation failed";
+        case NBX_ERR_STATE: return "call made in the wrong state";
+        default: return "unknown nbx status";
+    }
+}
+
+const char* nbx_last_error_detail(void) { return g_detail.c_str(); }
+
+int nbx_num_variants(void) { return num_variants(); }
+const char* nbx_variant_name(int variant) { return variant_name(variant); }
+int nbx_default_variant(void) { return default_variant(); }
+
+int nbx_device_count(int* count) {
+    if (!count) return fail(NBX_ERR_INVALID, "count is null");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount", __FILE__, __LINE__);
+    *count = n;
+    return n > 0 ? NBX_OK : fail(NBX_ERR_NO_DEVICE, "hipGetDeviceCount returned 0 devices");
+}
+
+int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_shards, int shard) {
+    if (!out) return fail(NBX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) return fail(NBX_ERR_INVALID, "bad shard / n_shards");
+    if (n_total > (size_t)1 << 31) return fail(NBX_ERR_INVALID, "n_total too large");
+    int ndev = 0;
+    int rc = nbx_device_count(&ndev);
+    if (rc != NBX_OK) return rc;
+    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
+    nbx_ctx* c = new (std::nothrow) nbx_ctx();
+    if (!c) return fail(NBX_ERR_ALLOC, "host allocation failed");
+    c->device = device; c->dim = dim; c->n_total = n_total; c->n_shards = n_shards; c->shard = shard;
+    c->shard_len = (n_total + (size_t)n_shards - 1) / (size_t)n_shards;
+    const size_t lo = (size_t)shard * c->shard_len;
+    c->count = lo >= n_total ? 0 : ((n_total - lo < c->shard_len) ? n_total - lo : c->shard_len);
+    size_t pad = (c->shard_len + kPadQuantum - 1) / kPadQuantum * kPadQuantum;
+    if (pad == 0) pad = kPadQuantum;
+    c->pad = (unsigned)pad;
+    c->variant = default_variant();
+#define CTX_TRY(expr)                                                            \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) { int r_ = fail_hip(e_, #expr, __FILE__, __LINE__); nbx_ctx_destroy(c); return r_; } \
+    } while (0)
+    CTX_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CTX_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CTX_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CTX_TRY(hipMalloc((void**)&c->x64, (size_t)dim * pad * sizeof(double)));
+    CTX_TRY(hipMalloc((void**)&c->v64, (size_t)dim * pad * sizeof(double)));
+    CTX_TRY(hipMalloc((void**)&c->m64, pad * sizeof(double)));
+    c->ev0.resize(kEventPairs); c->ev1.resize(kEventPairs);
+    for (int i = 0; i < kEventPairs; ++i) { c->ev0[i] = nullptr; c->ev1[i] = nullptr; }
+    for (int i = 0; i < kEventPairs; ++i) { CTX_TRY(hipEventCreate(&c->ev0[i])); CTX_TRY(hipEventCreate(&c->ev1[i])); }
+#undef CTX_TRY
+    *out = c;
+    return NBX_OK;
+}
+
+int nbx_ctx_destroy(nbx_ctx* c) {
+    if (!c) return NBX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_gather) { if (c->pos_all) (void)hipFree(c->pos_all); if (c->mass_all) (void)hipFree(c->mass_all); }
+    if (c->x64) (void)hipFree(c->x64);
+    if (c->v64) (void)hipFree(c->v64);
+    if (c->m64) (void)hipFree(c->m64);
+    if (c->acc) (void)hipFree(c->acc);
+    if (c->stage) (void)hipFree(c->stage);
+    for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return NBX_OK;
+}
+
+int nbx_ctx_set_stream(nbx_ctx* c, void* hip_stream) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return NBX_OK;
+}
+
+int nbx_ctx_set_gather_buffers(nbx_ctx* c, void* pos_all, void* mass_all) {
+    if (!c || !pos_all || !mass_all) return fail(NBX_ERR_INVALID, "null argument");
+    if (c->uploaded) return fail(NBX_ERR_STATE, "gather buffers must be set before upload");
+    if (c->own_gather) {
+        if (c->pos_all) (void)hipFree(c->pos_all);
+        if (c->mass_all) (void)hipFree(c->mass_all);
+    }
+    c->pos_all = (float*)pos_all;
+    c->mass_all = (float*)mass_all;
+    c->own_gather = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_gather_layout(const nbx_ctx* c, size_t* shard_len, size_t* shard_pad, void** pos_all, void** mass_all) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (shard_len) *shard_len = c->shard_len;
+    if (shard_pad) *shard_pad = c->pad;
+    if (pos_all) *pos_all = c->pos_all;
+    if (mass_all) *mass_all = c->mass_all;
+    return NBX_OK;
+}
+
+int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
+    if (!c || (!bodies && c->n_total)) return fail(NBX_ERR_INVALID, "null argument");
+    const size_t min_stride = (size_t)(2 * c->dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->pos_all) {
+        HIP_TRY(hipMalloc((void**)&c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)));
+        c->own_gather = true;
+    }
+    const size_t bytes = c->n_total * stride_bytes;
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(c->stage, bodies, bytes, hipMemcpyHostToDevice, c->stream));
+    PackArgs p;
+    p.raw = c->stage; p.stride_d = stride_bytes / sizeof(double); p.n_total = c->n_total;
+    p.shard_len = c->shard_len; p.pad = c->pad; p.n_shards = c->n_shards; p.shard = c->shard; p.dim = c->dim;
+    p.pos_all = c->pos_all; p.mass_all = c->mass_all; p.x64 = c->x64; p.v64 = c->v64; p.m64 = c->m64;
+    HIP_TRY(launch_pack(p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
+    c->uploaded = true;
+    c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_set_tuning(nbx_ctx* c, int source_splits, int variant) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (source_splits < 0 || source_splits > 64) return fail(NBX_ERR_INVALID, "source_splits must be in [0,64]");
+    if (variant < -1 || variant >= num_variants()) return fail(NBX_ERR_INVALID, "unknown kernel variant");
+    c->splits_user = source_splits > 0;
+    if (c->splits_user) c->splits = source_splits;
+    c->variant = variant < 0 ? default_variant() : variant;
+    c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies before computing accelerations");
+    if (which < NBX_SRC_ALL || which > NBX_SRC_REMOTE) return fail(NBX_ERR_INVALID, "bad source selector");
+    if (which == NBX_SRC_REMOTE && !c->have_accel) return fail(NBX_ERR_STATE, "REMOTE pass needs a preceding LOCAL pass");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (which != NBX_SRC_REMOTE) { rc = ensure_acc(c); if (rc) return rc; }
+    AccelLaunch L;
+    L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad;
+    L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
+    L.chunk_skip = INT_MAX; L.accumulate = 0;
+    if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
+    else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
+    else { L.chunk_first = 0; L.vchunks = c->n_shards - 1; L.chunk_skip = c->shard; L.accumulate = 1; }
+    if (L.vchunks == 0) return NBX_OK;  // REMOTE with a single shard: nothing to add
+    const bool timed = c->ev_used < kEventPairs;
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], c->stream));
+    HIP_TRY(launch_accel(c->dim, L, c->stream));
+    if (timed) { HIP_TRY(hipEventRecord(c->ev1[c->ev_used], c->stream)); ++c->ev_used; }
+    ++c->launches_since_query;
+    c->have_accel = true;
+    return NBX_OK;
+}
+
+int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->have_accel) return fail(NBX_ERR_STATE, "compute accelerations before kick_drift");
+    int rc = set_device(c);
+    if (rc) return rc;
+    KickDriftArgs k;
+    k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = G; k.dt = dt;
+    k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64;
+    k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
+    HIP_TRY(launch_kick_drift(k, c->stream));
+    c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (c->n_shards != 1) return fail(NBX_ERR_STATE, "nbx_ctx_step drives single-shard contexts only");
+    if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps < 0");
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
+        if (rc) return rc;
+        rc = nbx_ctx_kick_drift(c, G, dt);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_ctx_get_forces(nbx_ctx* c, double G, double* out) {
+    if (!c || (!out && c->count)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->have_accel) return fail(NBX_ERR_STATE, "no accelerations computed");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t bytes = c->count * c->dim * sizeof(double);
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    HIP_TRY(launch_export_forces(c->acc, c->splits, c->dim, c->pad, c->count, G, c->m64, c->stage, c->stream));
+    if (bytes) HIP_TRY(hipMemcpyAsync(out, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBX_OK;
+}
+
+int nbx_ctx_get_accel(nbx_ctx* c, float* out) {
+    if (!c || (!out && c->count)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->have_accel) return fail(NBX_ERR_STATE, "no accelerations computed");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t bytes = c->count * c->dim * sizeof(float);
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    HIP_TRY(launch_export_accel(c->acc, c->splits, c->dim, c->pad, c->count, (float*)c->stage, c->stream));
+    if (bytes) HIP_TRY(hipMemcpyAsync(out, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBX_OK;
+}
+
+int nbx_ctx_download_bodies(nbx_ctx* c, void* bodies, size_t stride_bytes) {
+    if (!c || (!bodies && c->count)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "nothing uploaded");
+    const size_t min_stride = (size_t)(2 * c->dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t w = 2 * (size_t)c->dim;
+    const size_t bytes = c->count * w * sizeof(double);
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    HIP_TRY(launch_export_state(c->x64, c->v64, c->dim, c->pad, c->count, c->stage, c->stream));
+    std::vector<double> host;
+    try { host.resize(c->count * w); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
+    if (bytes) HIP_TRY(hipMemcpyAsync(host.data(), c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    char* base = (char*)bodies + (size_t)c->shard * c->shard_len * stride_bytes;
+    for (size_t l = 0; l < c->count; ++l) std::memcpy(base + l * stride_bytes, &host[l * w], w * sizeof(double));
+    return NBX_OK;
+}
+
+int nbx_ctx_synchronize(nbx_ctx* c) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBX_OK;
+}
+
+int nbx_ctx_kernel_time(nbx_ctx* c, float* mean_ms, int* launches) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (int i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+        sum += ms;
+    }
+    if (mean_ms) *mean_ms = c->ev_used ? (float)(sum / c->ev_used) : 0.f;
+    if (launches) *launches = c->ev_used;
+    c->ev_used = 0;
+    c->launches_since_query = 0;
+    return NBX_OK;
+}
+
+// ---- one-shot entry points -------------------------------------------------------------------------
+
+int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, double G, int device,
+                           double* forces_out, float* kernel_ms) {
+    if ((!bodies || !forces_out) && n) return fail(NBX_ERR_INVALID, "null argument");
+    nbx_ctx* c = nullptr;
+    int rc = nbx_ctx_create(&c, device, dim, n, 1, 0);
+    if (rc) return rc;
+    rc = nbx_ctx_upload_bodies(c, bodies, stride_bytes);
+    if (!rc) rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
+    if (!rc) rc = nbx_ctx_get_forces(c, G, forces_out);
+    if (!rc && kernel_ms) rc = nbx_ctx_kernel_time(c, kernel_ms, nullptr);
+    nbx_ctx_destroy(c);
+    return rc;
+}
+
+int nbx_leapfrog(void* bodies, size_t n, int dim, size_t stride_bytes, double G, double dt, int nsteps, int device,
+                 float* kernel_ms_total) {
+    if (!bodies && n) return fail(NBX_ERR_INVALID, "null argument");
+    nbx_ctx* c = nullptr;
+    int rc = nbx_ctx_create(&c, device, dim, n, 1, 0);
+    if (rc) return rc;
+    rc = nbx_ctx_upload_bodies(c, bodies, stride_bytes);
+    if (!rc) rc = nbx_ctx_step(c, G, dt, nsteps);
+    if (!rc) rc = nbx_ctx_download_bodies(c, bodies, stride_bytes);
+    if (!rc && kernel_ms_total) {
+        float mean = 0.f; int cnt = 0;
+        rc = nbx_ctx_kernel_time(c, &mean, &cnt);
+        *kernel_ms_total = mean * (float)cnt;
+    }
+    nbx_ctx_destroy(c);
+    return rc;
+}
+
+}  // extern "C"

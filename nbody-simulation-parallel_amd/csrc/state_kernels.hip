@@ -1,0 +1,132 @@
+// state_kernels.hip -- K3/K4: layout pack/unpack at the boundary and the fused kick+drift step.
+//
+// All O(N), HBM-streaming kernels; one lane per body, SoA arrays so every access is coalesced.
+// The integrator state (position, velocity, mass of the own shard) is kept in fp64 and advanced
+// with exactly the reference's arithmetic (nbody-sim-new/methods.cpp:425-450); only the pair sum
+// feeding it is fp32.  Each drift also refreshes the shard's fp32 chunk of the exchange buffer.
+#include "nbx_internal.h"
+
+namespace nbx {
+namespace {
+
+// Sum the per-slice partial accelerations of body l, component k, in slice order (deterministic).
+__device__ __forceinline__ double sum_partials(const float* __restrict__ acc, int splits, int dim,
+                                               unsigned pad, int k, size_t l) {
+    double a = 0.0;
+    for (int s = 0; s < splits; ++s) a += (double)acc[((size_t)s * dim + k) * pad + l];
+    return a;
+}
+
+// K4: AoS fp64 Body<D> (body.h:8-11) -> SoA fp32 exchange buffers for every shard + fp64 state of
+// the own shard.  Pad entries become massless bodies at the origin.
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs p) {
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;  // index into [n_shards][pad]
+    if (b >= (size_t)p.n_shards * p.pad) return;
+    const int g = (int)(b / p.pad);
+    const size_t l = b - (size_t)g * p.pad;
+    const size_t id = (size_t)g * p.shard_len + l;
+    const bool real = (l < p.shard_len) && (id < p.n_total);
+    const double* __restrict__ src = p.raw + id * p.stride_d;
+    for (int k = 0; k < p.dim; ++k) {
+        const double x = real ? src[k] : 0.0;
+        p.pos_all[((size_t)g * p.dim + k) * p.pad + l] = (float)x;
+        if (g == p.shard) {
+            p.x64[(size_t)k * p.pad + l] = x;
+            p.v64[(size_t)k * p.pad + l] = real ? src[p.dim + k] : 0.0;
+        }
+    }
+    const double m = real ? src[2 * p.dim] : 0.0;
+    p.mass_all[(size_t)g * p.pad + l] = (float)m;
+    if (g == p.shard) p.m64[l] = m;
+}
+
+// K3: fused kick + drift (methods.cpp:436 then :448), fp64:
+//   F = -(G m) a ;  v += (F / m) * dt ;  x += v * dt ;  pos32 = (float)x
+__global__ __launch_bounds__(256) void kick_drift_kernel(KickDriftArgs a) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= a.count) return;
+    const double m = a.m64[l];
+    const double gm = a.G * m;
+    for (int k = 0; k < a.dim; ++k) {
+        const double acc = sum_partials(a.acc, a.splits, a.dim, a.pad, k, l);
+        const double F = -(gm * acc);
+        double v = a.v64[(size_t)k * a.pad + l];
+        double x = a.x64[(size_t)k * a.pad + l];
+        v += (F / m) * a.dt;
+        x += v * a.dt;
+        a.v64[(size_t)k * a.pad + l] = v;
+        a.x64[(size_t)k * a.pad + l] = x;
+        a.pos_chunk[(size_t)k * a.pad + l] = (float)x;
+    }
+}
+
+__global__ __launch_bounds__(256) void export_forces_kernel(const float* __restrict__ acc, int splits, int dim,
+                                                            unsigned pad, size_t count, double G,
+                                                            const double* __restrict__ m64,
+                                                            double* __restrict__ out) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= count) return;
+    const double gm = G * m64[l];
+    for (int k = 0; k < dim; ++k) out[l * dim + k] = -(gm * sum_partials(acc, splits, dim, pad, k, l));
+}
+
+__global__ __launch_bounds__(256) void export_accel_kernel(const float* __restrict__ acc, int splits, int dim,
+                                                           unsigned pad, size_t count, float* __restrict__ out) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= count) return;
+    for (int k = 0; k < dim; ++k) out[(size_t)k * count + l] = (float)sum_partials(acc, splits, dim, pad, k, l);
+}
+
+__global__ __launch_bounds__(256) void export_state_kernel(const double* __restrict__ x64,
+                                                           const double* __restrict__ v64, int dim,
+                                                           unsigned pad, size_t count, double* __restrict__ out) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= count) return;
+    for (int k = 0; k < dim; ++k) {
+        out[l * 2 * dim + k] = x64[(size_t)k * pad + l];
+        out[l * 2 * dim + dim + k] = v64[(size_t)k * pad + l];
+    }
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t launch_pack(const PackArgs& p, hipStream_t stream) {
+    const size_t total = (size_t)p.n_shards * p.pad;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_kick_drift(const KickDriftArgs& k, hipStream_t stream) {
+    if (k.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(kick_drift_kernel, dim3(blocks_for(k.count)), dim3(256), 0, stream, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_forces(const float* acc, int splits, int dim, unsigned pad, size_t count, double G,
+                                const double* m64, double* forces_out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(export_forces_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, acc, splits, dim, pad,
+                       count, G, m64, forces_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned pad, size_t count,
+                               float* accel_out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(export_accel_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, acc, splits, dim, pad,
+                       count, accel_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_state(const double* x64, const double* v64, int dim, unsigned pad, size_t count,
+                               double* state_out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(export_state_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, x64, v64, dim, pad,
+                       count, state_out);
+    return hipGetLastError();
+}
+
+}  // namespace nbx

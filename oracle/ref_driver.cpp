@@ -1,0 +1,123 @@
+// ref_driver.cpp -- thin extern "C" shim over the REFERENCE's own object code.
+//
+// TEST INFRASTRUCTURE ONLY.  Built by oracle/build_ref.sh (only where /root/reference exists)
+// into oracle/_ref/libnbody_ref.so together with the reference's methods.cpp compiled from where
+// it lies.  Nothing from the reference is copied into this repository: this file only #includes
+// the reference headers at build time and forwards plain pointers to the reference's templates.
+//
+// Used to (1) pin oracle/nbody_oracle.c against the true reference, (2) generate the golden
+// vectors under tests/golden/, (3) optionally serve as bench.py's cpu_baseline kind "reference".
+#include "methods.h"   // /root/reference/nbody-sim-new/methods.h (via -I)
+
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <vector>
+
+namespace {
+template <int D>
+std::vector<Body<D>> wrap(const double* raw, size_t n) {
+    static_assert(sizeof(Body<D>) == sizeof(double) * (2 * D + 1), "Body<D> layout");
+    std::vector<Body<D>> b(n);
+    if (n) std::memcpy(static_cast<void*>(b.data()), raw, n * sizeof(Body<D>));
+    return b;
+}
+template <int D>
+void unwrap(const std::vector<Vector<D>>& f, double* out) {
+    static_assert(sizeof(Vector<D>) == sizeof(double) * D, "Vector<D> layout");
+    if (!f.empty()) std::memcpy(out, static_cast<const void*>(f.data()), f.size() * sizeof(Vector<D>));
+}
+template <int D>
+int forces(int variant, const double* raw, size_t n, double* out) {
+    auto b = wrap<D>(raw, n);
+    std::vector<Vector<D>> f;
+    switch (variant) {
+        case 0: f = brute_force_seq_n_body<D>(b); break;
+        case 1: f = brute_force_omp_n_body_1<D>(b); break;
+        case 2: f = brute_force_omp_n_body_2<D>(b); break;
+        default: return -1;
+    }
+    unwrap<D>(f, out);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int ref_sizeof_body(int D) { return D == 2 ? (int)sizeof(Body<2>) : (int)sizeof(Body<3>); }
+double ref_G() { return G; }
+
+// variant: 0 = brute_force_seq_n_body, 1 = brute_force_omp_n_body_1, 2 = brute_force_omp_n_body_2
+int ref_brute_force(int variant, const double* bodies, size_t n, int D, double* out) {
+    if (D == 2) return forces<2>(variant, bodies, n, out);
+    if (D == 3) return forces<3>(variant, bodies, n, out);
+    return -1;
+}
+
+int ref_update_body_velocities(double* bodies, const double* f, size_t n, int D, double dt) {
+    if (D == 2) {
+        auto b = wrap<2>(bodies, n);
+        std::vector<Vector<2>> fv(n);
+        if (n) std::memcpy(static_cast<void*>(fv.data()), f, n * sizeof(Vector<2>));
+        update_body_velocities<2>(b, fv, dt);
+        if (n) std::memcpy(bodies, static_cast<const void*>(b.data()), n * sizeof(Body<2>));
+        return 0;
+    }
+    if (D == 3) {
+        auto b = wrap<3>(bodies, n);
+        std::vector<Vector<3>> fv(n);
+        if (n) std::memcpy(static_cast<void*>(fv.data()), f, n * sizeof(Vector<3>));
+        update_body_velocities<3>(b, fv, dt);
+        if (n) std::memcpy(bodies, static_cast<const void*>(b.data()), n * sizeof(Body<3>));
+        return 0;
+    }
+    return -1;
+}
+
+int ref_update_body_positions(double* bodies, size_t n, int D, double dt) {
+    if (D == 2) {
+        auto b = wrap<2>(bodies, n);
+        update_body_positions<2>(b, dt);
+        if (n) std::memcpy(bodies, static_cast<const void*>(b.data()), n * sizeof(Body<2>));
+        return 0;
+    }
+    if (D == 3) {
+        auto b = wrap<3>(bodies, n);
+        update_body_positions<3>(b, dt);
+        if (n) std::memcpy(bodies, static_cast<const void*>(b.data()), n * sizeof(Body<3>));
+        return 0;
+    }
+    return -1;
+}
+
+// Same distributions and draw order as the reference generator (utils.h:107-135), which cannot
+// be called for fixtures because it seeds from std::random_device.  libstdc++'s own mt19937 and
+// uniform_real_distribution are used here, so this also pins the oracle's restated generator.
+int ref_generate_random_bodies_seeded(uint32_t seed, size_t n, int D, double* out) {
+    std::mt19937 gen(seed);
+    std::uniform_real_distribution<double> position_dist(1, 10000000.0);
+    std::uniform_real_distribution<double> velocity_dist(-10.0, 10.0);
+    std::uniform_real_distribution<double> mass_dist(1, 100000000.0);
+    const size_t stride = 2 * (size_t)D + 1;
+    for (size_t i = 0; i < n; ++i) {
+        for (int d = 0; d < D; ++d) {
+            out[i * stride + d] = position_dist(gen);
+            out[i * stride + D + d] = velocity_dist(gen);
+        }
+        out[i * stride + 2 * D] = mass_dist(gen);
+    }
+    return 0;
+}
+
+double ref_compute_accuracy(const double* f, const double* r, size_t n, int D) {
+    if (D == 2) {
+        std::vector<Vector<2>> a(n), b(n);
+        if (n) { std::memcpy(static_cast<void*>(a.data()), f, n * sizeof(Vector<2>)); std::memcpy(static_cast<void*>(b.data()), r, n * sizeof(Vector<2>)); }
+        return compute_accuracy_omp<2>(a, b);
+    }
+    std::vector<Vector<3>> a(n), b(n);
+    if (n) { std::memcpy(static_cast<void*>(a.data()), f, n * sizeof(Vector<3>)); std::memcpy(static_cast<void*>(b.data()), r, n * sizeof(Vector<3>)); }
+    return compute_accuracy_omp<3>(a, b);
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) and, where it was built, to the reference's
+own object code (oracle/_ref/libnbody_ref.so).  TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libnbody_ref.so")
+
+_P = ctypes.POINTER(ctypes.c_double)
+_sz = ctypes.c_size_t
+
+
+def _p(a):
+    return a.ctypes.data_as(_P)
+
+
+def build_oracle():
+    """Compile oracle/nbody_oracle.c (gcc) if the shared object is missing or stale."""
+    src = os.path.join(ORACLE_DIR, "nbody_oracle.c")
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    def __init__(self):
+        build_oracle()
+        self.lib = ctypes.CDLL(ORACLE_SO)
+        self.lib.oracle_G.restype = ctypes.c_double
+        self.lib.oracle_compute_accuracy.restype = ctypes.c_double
+        self.G = self.lib.oracle_G()
+
+    @staticmethod
+    def _dim(bodies):
+        assert bodies.dtype == np.float64 and bodies.ndim == 2 and bodies.shape[1] in (5, 7) and bodies.flags["C_CONTIGUOUS"]
+        return (bodies.shape[1] - 1) // 2
+
+    def generate(self, seed: int, n: int, dim: int) -> np.ndarray:
+        b = np.zeros((n, 2 * dim + 1), dtype=np.float64)
+        rc = self.lib.oracle_generate_random_bodies(ctypes.c_uint32(seed), _sz(n), dim, _p(b))
+        assert rc == 0
+        return b
+
+    def round_inputs_to_f32(self, bodies: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(bodies.copy())
+        self.lib.oracle_round_inputs_to_f32(_p(b), _sz(b.shape[0]), self._dim(b))
+        return b
+
+    def _forces(self, fn, bodies):
+        d = self._dim(bodies)
+        f = np.zeros((bodies.shape[0], d), dtype=np.float64)
+        rc = fn(_p(bodies), _sz(bodies.shape[0]), d, _p(f))
+        assert rc == 0
+        return f
+
+    def brute_force_seq(self, bodies):
+        return self._forces(self.lib.oracle_brute_force_seq, bodies)
+
+    def brute_force_omp_1(self, bodies):
+        return self._forces(self.lib.oracle_brute_force_omp_1, bodies)
+
+    def brute_force_omp_2(self, bodies):
+        return self._forces(self.lib.oracle_brute_force_omp_2, bodies)
+
+    def force_rows_omp_2(self, bodies, rows):
+        d = self._dim(bodies)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.zeros((rows.size, d), dtype=np.float64)
+        rc = self.lib.oracle_force_rows_omp_2(_p(bodies), _sz(bodies.shape[0]), d,
+                                              rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _sz(rows.size), _p(out))
+        assert rc == 0
+        return out
+
+    def update_body_velocities(self, bodies, forces, dt):
+        assert forces.flags["C_CONTIGUOUS"] and forces.dtype == np.float64
+        self.lib.oracle_update_body_velocities(_p(bodies), _p(forces), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(dt))
+
+    def update_body_positions(self, bodies, dt):
+        self.lib.oracle_update_body_positions(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(dt))
+
+    def leapfrog(self, bodies, dt, nsteps, variant=2):
+        rc = self.lib.oracle_leapfrog(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(dt), nsteps, variant)
+        assert rc == 0
+
+    def compute_accuracy(self, forces, ref):
+        return self.lib.oracle_compute_accuracy(_p(np.ascontiguousarray(forces)), _p(np.ascontiguousarray(ref)),
+                                                _sz(forces.shape[0]), forces.shape[1])
+
+    def energy(self, bodies):
+        out = np.zeros(2)
+        self.lib.oracle_energy(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), _p(out))
+        return out[0], out[1]
+
+    def num_threads(self):
+        return self.lib.oracle_num_threads()
+
+
+class Reference:
+    """The reference's own object code (only where oracle/build_ref.sh produced it).  The library
+    leaves FMM members the reference never defines unresolved, so it must be bound lazily:
+    ctypes forces RTLD_NOW, hence the explicit dlopen(RTLD_LAZY)."""
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO)
+        libc = ctypes.CDLL(None)
+        libc.dlopen.restype = ctypes.c_void_p
+        libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        h = libc.dlopen(REF_SO.encode(), 1)  # RTLD_LAZY
+        if not h:
+            raise OSError("dlopen failed for " + REF_SO)
+        self.lib = ctypes.CDLL(REF_SO, handle=h)
+        self.lib.ref_G.restype = ctypes.c_double
+        self.lib.ref_compute_accuracy.restype = ctypes.c_double
+
+    def G(self):
+        return self.lib.ref_G()
+
+    def sizeof_body(self, dim):
+        return self.lib.ref_sizeof_body(dim)
+
+    def generate(self, seed, n, dim):
+        b = np.zeros((n, 2 * dim + 1), dtype=np.float64)
+        assert self.lib.ref_generate_random_bodies_seeded(ctypes.c_uint32(seed), _sz(n), dim, _p(b)) == 0
+        return b
+
+    def brute_force(self, variant, bodies):
+        d = (bodies.shape[1] - 1) // 2
+        f = np.zeros((bodies.shape[0], d), dtype=np.float64)
+        assert self.lib.ref_brute_force(variant, _p(bodies), _sz(bodies.shape[0]), d, _p(f)) == 0
+        return f
+
+    def update_body_velocities(self, bodies, forces, dt):
+        d = (bodies.shape[1] - 1) // 2
+        assert self.lib.ref_update_body_velocities(_p(bodies), _p(forces), _sz(bodies.shape[0]), d, ctypes.c_double(dt)) == 0
+
+    def update_body_positions(self, bodies, dt):
+        d = (bodies.shape[1] - 1) // 2
+        assert self.lib.ref_update_body_positions(_p(bodies), _sz(bodies.shape[0]), d, ctypes.c_double(dt)) == 0
+
+    def compute_accuracy(self, forces, ref):
+        return self.lib.ref_compute_accuracy(_p(np.ascontiguousarray(forces)), _p(np.ascontiguousarray(ref)),
+                                             _sz(forces.shape[0]), forces.shape[1])
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def accel_errors(forces, ref_forces, masses, G):
+    """Accuracy protocol of SURVEY 8d: accelerations a = F/m; returns (max over bodies of
+    |da|_2/|a_ref|_2, max-abs component error of a)."""
+    a = forces / masses[:, None]
+    r = ref_forces / masses[:, None]
+    num = np.sqrt(((a - r) ** 2).sum(axis=1))
+    den = np.sqrt((r ** 2).sum(axis=1))
+    rel = num / np.where(den > 0, den, 1.0)
+    return float(rel.max()), float(np.abs(a - r).max())
