@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-interactions/s of the MI355X all-pairs force + kick/drift step.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is launched as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2]/[3]): N = 1,048,576 bodies, 3D, uniform-random with the
+reference's generator ranges (nbody-sim-new/utils.h:113-115), fp32 device arithmetic.  A "step" is one
+pass of the hot path over all bodies: all-pairs force evaluation (N^2 ordered pairs, split over the
+ranks' target shards) + fused kick/drift (+ the per-step RCCL all-gather of positions when N > 1).
+value = N^2 * K / t, inputs resident in HBM before the timed region.  Total work is fixed as ranks are
+added => "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# host threads for the CPU baseline: the GPU box's CPU share for one GPU is 16 hardware threads
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
+FLOP_PER_INTERACTION = 20          # SURVEY 8d convention (3 sub, 5 r^2, rcp, 3 mul, 6 fma-acc, 2 guard)
+PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = FP32 matrix
+HBM_PEAK_GBPS = 8000.0
+
+
+def cpu_baseline(n_bodies, dim, seed, budget_s=12.0):
+    """Reported baseline (not the target): the reference's own brute_force_omp_n_body_2 object code
+    (oracle/_ref, kind "reference") or the oracle port of it (kind "port") on a bounded sample of
+    the same workload, timed on this host's cores."""
+    import numpy as np
+    from oracle_lib import Oracle, Reference, have_reference
+    o = Oracle()
+    threads = o.num_threads()
+    bodies = o.generate(seed, n_bodies, dim)
+    # calibrate with the port on a few rows, then size the sample for ~budget_s
+    rows = np.arange(0, 2048, dtype=np.int64)
+    t0 = time.perf_counter()
+    o.force_rows_omp_2(bodies, rows)
+    rate = rows.size * n_bodies / (time.perf_counter() - t0)
+    if have_reference():
+        try:
+            ref = Reference()
+            n_s = int(min(n_bodies, max(4096, (rate * budget_s) ** 0.5)))
+            n_s = 1 << (n_s.bit_length() - 1)
+            sub = np.ascontiguousarray(bodies[:n_s])
+            t0 = time.perf_counter()
+            ref.brute_force(2, sub)
+            dt = time.perf_counter() - t0
+            return {"value": n_s * (n_s - 1) / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "reference",
+                    "sample": f"reference brute_force_omp_n_body_2<{dim}> object code (oracle/_ref) on the first {n_s} bodies "
+                              f"of the workload, {n_s*(n_s-1):.3e} pair evaluations in {dt:.2f} s, OMP_NUM_THREADS={threads}"}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write(f"[bench] reference baseline unavailable ({e}); using the oracle port\n")
+    nrows = int(min(n_bodies, max(2048, rate * budget_s / n_bodies)))
+    rows = np.linspace(0, n_bodies - 1, nrows).astype(np.int64)
+    t0 = time.perf_counter()
+    o.force_rows_omp_2(bodies, rows)
+    dt = time.perf_counter() - t0
+    return {"value": nrows * (n_bodies - 1) / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "port",
+            "sample": f"oracle port of brute_force_omp_n_body_2<{dim}>: {nrows} target rows x {n_bodies} sources "
+                      f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bodies", type=int, default=1 << 20, help="N (default 2^20 = BASELINE metric config)")
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--dt", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1, help="force-kernel variant id (-1: library default)")
+    ap.add_argument("--splits", type=int, default=0, help="source slices (0: automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import nbody_amd as nbx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # synthetic bodies, identical on every rank (reference generator ranges; seeded)
+    from oracle_lib import Oracle  # generator only: inputs, not the measured path
+    bodies = Oracle().generate(args.seed, args.bodies, args.dim)
+    N = args.bodies
+
+    system = nbx.package.dist.make_hip_system(bodies, args.dim, rank=rank, world_size=world, device_index=local_rank,
+                                             variant=args.variant, source_splits=args.splits)
+    be = system.be
+    G = nbx.REFERENCE_G
+
+    def sync_all():
+        be.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        system.step(args.dt, G, 1)
+    sync_all()
+    be.kernel_time()  # reset the force-kernel event log
+    sync_all()
+    t0 = time.perf_counter()
+    system.step(args.dt, G, args.steps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms, launches = be.kernel_time()  # HIP events on the stream the kernels ran on
+
+    result = None
+    if rank == 0:
+        interactions = float(N) * float(N) * args.steps
+        value = interactions / elapsed
+        my_pairs_per_launch = float(system.layout.count) * float(N) / (1 if world == 1 else 1)  # per step on this rank
+        launches_per_step = 1 if world == 1 else 2
+        kern_s_per_step = kern_ms * 1e-3 * launches_per_step
+        achieved_tflops = my_pairs_per_launch * FLOP_PER_INTERACTION / kern_s_per_step / 1e12
+        lib = nbx.load_library()
+        vid = args.variant if args.variant >= 0 else lib.nbx_default_variant()
+        result = {
+            "metric": "body-pair interactions/sec at N=2^20 (all-pairs force + kick/drift step)" if N == 1 << 20
+                      else f"body-pair interactions/sec at N={N}",
+            "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"N={N} {args.dim}D uniform-random bodies (reference generator ranges, seed {args.seed}), "
+                                   "one all-pairs force evaluation + fused kick/drift per step",
+                       "n_bodies": N, "dim": args.dim, "lds_tile": 256, "kernel_variant": lib.nbx_variant_name(vid).decode(),
+                       "parallelism": "1 GPU" if world == 1 else f"{world} target shards, RCCL all-gather of positions per step"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "accel_lds_kernel/accel_smem_kernel (force)", "kernel_ms_mean": kern_ms,
+                         "kernel_launches_timed": launches, "flop_per_interaction": FLOP_PER_INTERACTION,
+                         "interactions_per_launch": my_pairs_per_launch / launches_per_step,
+                         "note": "binding roofline is fp32 VALU issue (no MFMA, HBM-light); peak = MI355X fp32 vector = fp32 matrix peak",
+                         "hbm": {"algorithmic_bytes_per_launch": 28.0 * N / world if world == 1 else (16.0 * N + 12.0 * system.layout.count),
+                                 "achieved_GBps": (28.0 * N if world == 1 else (16.0 * N + 12.0 * system.layout.count)) / kern_s_per_step / 1e9,
+                                 "peak_GBps": HBM_PEAK_GBPS}},
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)
+        print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

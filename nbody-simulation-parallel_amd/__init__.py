@@ -12,3 +12,12 @@ from .capi import (  # noqa: F401
     ABI, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE, Context, NbxError,
     body_stride, brute_force_hip_n_body, device_count, leapfrog_hip_n_body, load_library, variants,
 )
+from . import sharding  # noqa: E402,F401
+
+
+def __getattr__(name):
+    # dist.py imports torch; load it only when asked for
+    if name == "dist":
+        import importlib
+        return importlib.import_module(__name__ + ".dist")
+    raise AttributeError(name)

@@ -128,7 +128,7 @@ def brute_force_hip_n_body(bodies: np.ndarray, G: float = REFERENCE_G, device: i
     n = b.shape[0]
     out = np.empty((n, dim), dtype=np.float64)
     ms = ctypes.c_float(0.0)
-    rc = lib.nbx_brute_force_forces(b.ctypes.data, n, dim, b.strides[0], G, device, out.ctypes.data,
+    rc = lib.nbx_brute_force_forces(b.ctypes.data, n, dim, b.shape[1] * 8, G, device, out.ctypes.data,
                                     ctypes.byref(ms))
     _check(lib, rc, "nbx_brute_force_forces")
     return (out, ms.value) if return_kernel_ms else out
@@ -140,7 +140,7 @@ def leapfrog_hip_n_body(bodies: np.ndarray, dt: float, nsteps: int, G: float = R
     lib = load_library()
     b, dim = _as_bodies(bodies, writable=True)
     ms = ctypes.c_float(0.0)
-    rc = lib.nbx_leapfrog(b.ctypes.data, b.shape[0], dim, b.strides[0], G, dt, nsteps, device, ctypes.byref(ms))
+    rc = lib.nbx_leapfrog(b.ctypes.data, b.shape[0], dim, b.shape[1] * 8, G, dt, nsteps, device, ctypes.byref(ms))
     _check(lib, rc, "nbx_leapfrog")
     return ms.value
 
@@ -196,7 +196,7 @@ class Context:
         b, dim = _as_bodies(bodies)
         if dim != self.dim or b.shape[0] != self.n_total:
             raise ValueError("bodies shape does not match the context")
-        self._ck(self.lib.nbx_ctx_upload_bodies(self.h, b.ctypes.data, b.strides[0]), "nbx_ctx_upload_bodies")
+        self._ck(self.lib.nbx_ctx_upload_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_ctx_upload_bodies")
 
     def compute_accel(self, which: int = SRC_ALL):
         self._ck(self.lib.nbx_ctx_compute_accel(self.h, which), "nbx_ctx_compute_accel")
@@ -221,7 +221,7 @@ class Context:
         b, dim = _as_bodies(bodies, writable=True)
         if dim != self.dim or b.shape[0] != self.n_total:
             raise ValueError("bodies shape does not match the context")
-        self._ck(self.lib.nbx_ctx_download_bodies(self.h, b.ctypes.data, b.strides[0]), "nbx_ctx_download_bodies")
+        self._ck(self.lib.nbx_ctx_download_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_ctx_download_bodies")
 
     def synchronize(self):
         self._ck(self.lib.nbx_ctx_synchronize(self.h), "nbx_ctx_synchronize")

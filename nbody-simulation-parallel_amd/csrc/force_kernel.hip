@@ -16,8 +16,10 @@
 //     v_rcp, v_mul x2, v_fma x3); packed fp32 buys nothing on gfx950 (measured: v_pk_fma_f32 issues
 //     at half the v_fma_f32 rate -- profiles/ubench_valu_r1.txt) and MFMA does not apply (no
 //     contraction: the kernel is an element-wise map with a reciprocal in the middle);
-//   * two-level summation: partial sums over one 256-source tile are flushed into a second fp32
-//     accumulator, which keeps the max relative error ~2e-6 at N = 2^20 (naive: ~3e-4).
+//   * two-level summation: fp32 partial sums over one 256-source tile are flushed into an fp64
+//     second-level accumulator (3 v_add_f64 per 256 pairs per target: free), which keeps the error
+//     at the level of the 256-term inner sums whatever N is (a naive fp32 running sum: ~3e-4 at
+//     N = 131,072; an fp32 second level: 1.6e-6 of the magnitude sum at N = 2^20, measured).
 //   * grid = (target blocks, source slices): small shards are cut along the source list so the
 //     launch still covers all 1024 SIMDs; slice results land in acc[slice] and are summed in a
 //     fixed order by the consumer kernels (deterministic, no atomics).
@@ -98,14 +100,15 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
-    float ix[TPL], iy[TPL], iz[TPL], ox[TPL], oy[TPL], oz[TPL];
+    float ix[TPL], iy[TPL], iz[TPL];
+    double ox[TPL], oy[TPL], oz[TPL];  // second-level accumulators: one fp64 add per 256 pairs
 #pragma unroll
     for (int q = 0; q < TPL; ++q) {
         const unsigned i = tgt0 + q * 256u;
         ix[q] = tp[i];
         iy[q] = tp[(size_t)a.pad + i];
         iz[q] = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
-        ox[q] = oy[q] = oz[q] = 0.0f;
+        ox[q] = oy[q] = oz[q] = 0.0;
     }
 
     unsigned t = blockIdx.y * a.tiles_per_split;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
                 interact<D, GUARD>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
         }
 #pragma unroll
-        for (int q = 0; q < TPL; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
+        for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
         buf ^= 1;
     }
 
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     for (int q = 0; q < TPL; ++q) {
         const unsigned i = tgt0 + q * 256u;
         if (a.accumulate) {
-            out[i] += ox[q];
-            out[(size_t)a.pad + i] += oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] += oz[q];
+            out[i] = (float)((double)out[i] + ox[q]);
+            out[(size_t)a.pad + i] = (float)((double)out[(size_t)a.pad + i] + oy[q]);
+            if (D == 3) out[2 * (size_t)a.pad + i] = (float)((double)out[2 * (size_t)a.pad + i] + oz[q]);
         } else {
-            out[i] = ox[q];
-            out[(size_t)a.pad + i] = oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] = oz[q];
+            out[i] = (float)ox[q];
+            out[(size_t)a.pad + i] = (float)oy[q];
+            if (D == 3) out[2 * (size_t)a.pad + i] = (float)oz[q];
         }
     }
 }
@@ -178,14 +181,15 @@ __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
     const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
-    float ix[TPL], iy[TPL], iz[TPL], ox[TPL], oy[TPL], oz[TPL];
+    float ix[TPL], iy[TPL], iz[TPL];
+    double ox[TPL], oy[TPL], oz[TPL];  // second-level accumulators: one fp64 add per 256 pairs
 #pragma unroll
     for (int q = 0; q < TPL; ++q) {
         const unsigned i = tgt0 + q * 256u;
         ix[q] = tp[i];
         iy[q] = tp[(size_t)a.pad + i];
         iz[q] = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
-        ox[q] = oy[q] = oz[q] = 0.0f;
+        ox[q] = oy[q] = oz[q] = 0.0;
     }
 
     unsigned t = blockIdx.y * a.tiles_per_split;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
                     interact<D, GUARD>(sx[j], sy[j], sz[j], sm[j], ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
         }
 #pragma unroll
-        for (int q = 0; q < TPL; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
+        for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
         w.next(a.tiles_per_chunk);
     }
 
@@ -230,13 +234,13 @@ __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
     for (int q = 0; q < TPL; ++q) {
         const unsigned i = tgt0 + q * 256u;
         if (a.accumulate) {
-            out[i] += ox[q];
-            out[(size_t)a.pad + i] += oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] += oz[q];
+            out[i] = (float)((double)out[i] + ox[q]);
+            out[(size_t)a.pad + i] = (float)((double)out[(size_t)a.pad + i] + oy[q]);
+            if (D == 3) out[2 * (size_t)a.pad + i] = (float)((double)out[2 * (size_t)a.pad + i] + oz[q]);
         } else {
-            out[i] = ox[q];
-            out[(size_t)a.pad + i] = oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] = oz[q];
+            out[i] = (float)ox[q];
+            out[(size_t)a.pad + i] = (float)oy[q];
+            if (D == 3) out[2 * (size_t)a.pad + i] = (float)oz[q];
         }
     }
 }

@@ -1,0 +1,157 @@
+"""One process per GPU: sharded all-pairs stepping over torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" for the CPU rehearsal in tests/).
+
+The reference is single-process (no MPI/NCCL anywhere); this layer is new.  Per step and
+per rank:
+
+    comm stream   : all-gather of every rank's freshly drifted fp32 position chunk  (12 B/body)
+    compute stream: force kernel over the rank's OWN chunk of sources  -- needs no remote data,
+                    so it runs while the collective is in flight --, then (after the collective)
+                    the force kernel over the other ranks' chunks, accumulated on top, then the
+                    fused fp64 kick+drift, which rewrites this rank's chunk for the next exchange.
+
+Masses never change, so they are distributed once (every rank uploads the full initial array).
+The compute back end is an object with the five methods of `HipShardBackend`; the product back end
+calls the HIP library through its C ABI and has no CPU fallback.  tests/ substitutes a numpy double
+to rehearse the orchestration over gloo.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+from .sharding import ShardLayout
+
+
+class HipShardBackend:
+    """Shard compute on one MI355X: kernels via libnbody_hip.so, buffers and streams via torch."""
+
+    def __init__(self, bodies: np.ndarray, layout: ShardLayout, device_index: int, variant: int = -1,
+                 source_splits: int = 0):
+        if not torch.cuda.is_available():
+            raise capi.NbxError(capi.NBX_ERR_NO_DEVICE, "HipShardBackend", "no GPU visible to torch; there is no CPU fallback")
+        self.layout = layout
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.ctx = capi.Context(layout.n_total, layout.dim, device=device_index, n_shards=layout.n_shards, shard=layout.shard)
+        assert self.ctx.shard_pad == layout.shard_pad and self.ctx.shard_len == layout.shard_len
+        # exchange buffers live in torch memory so RCCL (through torch.distributed) and the kernels share them
+        self.pos_all = torch.zeros(layout.pos_all_shape(), dtype=torch.float32, device=self.device)
+        self.mass_all = torch.zeros(layout.mass_all_shape(), dtype=torch.float32, device=self.device)
+        self.ctx.set_gather_buffers(self.pos_all.data_ptr(), self.mass_all.data_ptr())
+        self.compute_stream = torch.cuda.Stream(device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device)
+        self.ctx.set_stream(self.compute_stream.cuda_stream)
+        self.ctx.set_tuning(source_splits, variant)
+        torch.cuda.synchronize(self.device)  # zero fills done before the library's stream writes
+        self.ctx.upload(bodies)
+
+    # -- the five operations the orchestrator needs --
+    def accel_local(self):
+        self.ctx.compute_accel(capi.SRC_LOCAL)
+
+    def accel_remote(self):
+        self.ctx.compute_accel(capi.SRC_REMOTE)
+
+    def kick_drift(self, G: float, dt: float):
+        self.ctx.kick_drift(dt, G)
+
+    def start_exchange(self, group):
+        """Launch the position all-gather on the comm stream, ordered after everything already
+        queued on the compute stream (the previous drift), and return the work handle."""
+        if self.layout.n_shards == 1:
+            return None
+        self.comm_stream.wait_stream(self.compute_stream)
+        with torch.cuda.stream(self.comm_stream):
+            return dist.all_gather_into_tensor(self.pos_all.view(-1), self.pos_all[self.layout.shard].view(-1),
+                                               group=group, async_op=True)
+
+    def finish_exchange(self, work):
+        if work is None:
+            return
+        with torch.cuda.stream(self.comm_stream):
+            work.wait()
+        self.compute_stream.wait_stream(self.comm_stream)
+
+    # -- results --
+    def forces(self, G: float) -> np.ndarray:
+        return self.ctx.forces(G)
+
+    def download_into(self, bodies: np.ndarray):
+        self.ctx.download(bodies)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+        torch.cuda.synchronize(self.device)
+
+    def kernel_time(self):
+        return self.ctx.kernel_time()
+
+    def close(self):
+        self.ctx.close()
+
+
+class ShardedNBody:
+    """The stepping loop of one rank.  `backend` supplies the shard compute (see module docstring)."""
+
+    def __init__(self, backend, layout: ShardLayout, group=None):
+        self.be = backend
+        self.layout = layout
+        self.group = group
+        if layout.n_shards > 1:
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed must be initialised for n_shards > 1")
+            ws = dist.get_world_size(group)
+            if ws != layout.n_shards or dist.get_rank(group) != layout.shard:
+                raise ValueError(f"layout ({layout.shard}/{layout.n_shards}) does not match the process group "
+                                 f"({dist.get_rank(group)}/{ws})")
+
+    def compute_forces(self):
+        """One force evaluation for this rank's targets against all N sources (positions as they
+        stand in the exchange buffer after the last drift)."""
+        work = self.be.start_exchange(self.group)
+        self.be.accel_local()
+        self.be.finish_exchange(work)
+        if self.layout.n_shards > 1:
+            self.be.accel_remote()
+
+    def step(self, dt: float, G: float = capi.REFERENCE_G, nsteps: int = 1):
+        for _ in range(nsteps):
+            self.compute_forces()
+            self.be.kick_drift(G, dt)
+
+    def forces(self, G: float = capi.REFERENCE_G) -> np.ndarray:
+        return self.be.forces(G)
+
+    def gather_bodies(self, bodies: np.ndarray) -> np.ndarray:
+        """Assemble the full Body<D> array on every rank from the ranks' shards (host side, fp64)."""
+        out = np.ascontiguousarray(bodies).copy()
+        self.be.download_into(out)
+        if self.layout.n_shards == 1:
+            return out
+        lo, hi = self.layout.bounds()
+        mine = torch.from_numpy(out[lo:hi].copy())
+        width = out.shape[1]
+        padded = torch.zeros((self.layout.shard_len, width), dtype=torch.float64)
+        padded[: hi - lo] = mine
+        use_cuda = dist.get_backend(self.group) == "nccl"
+        if use_cuda:
+            padded = padded.cuda()
+        allb = torch.zeros((self.layout.n_shards, self.layout.shard_len, width), dtype=torch.float64, device=padded.device)
+        dist.all_gather_into_tensor(allb.view(-1), padded.view(-1), group=self.group)
+        allb = allb.cpu().numpy()
+        for g in range(self.layout.n_shards):
+            glo, ghi = self.layout.bounds(g)
+            out[glo:ghi] = allb[g, : ghi - glo]
+        return out
+
+
+def make_hip_system(bodies: np.ndarray, dim: int, rank: int = 0, world_size: int = 1, device_index: Optional[int] = None,
+                    group=None, variant: int = -1, source_splits: int = 0) -> ShardedNBody:
+    layout = ShardLayout(n_total=bodies.shape[0], n_shards=world_size, shard=rank, dim=dim)
+    be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits)
+    return ShardedNBody(be, layout, group)

@@ -330,6 +330,31 @@ int oracle_energy(const double* bodies, size_t n, int D, double* out) {
     return 0;
 }
 
+/* S_i = sum_j |f_ij| (sum of pair-force magnitudes on body i): the scale against which a rounded
+ * evaluation of the cancelling sum F_i = -sum_j f_ij can be judged; kappa_i = S_i/|F_i| is the
+ * condition number of that sum.  rows == NULL: all bodies. */
+int oracle_force_magnitude_sums(const double* bodies, size_t n, int D, const int64_t* rows, size_t nrows, double* out) {
+    if (D != 2 && D != 3) return -1;
+    const size_t cnt = rows ? nrows : n;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t r = 0; r < cnt; ++r) {
+        const size_t i = rows ? (size_t)rows[r] : r;
+        const double* pi = POS(bodies, i, D);
+        const double mi = MASS(bodies, i, D);
+        double s = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            if (i == j) continue;
+            double f[3];
+            if (!pair_force(pi, POS(bodies, j, D), mi, MASS(bodies, j, D), D, f)) continue;
+            double m2 = 0.0;
+            for (int k = 0; k < D; ++k) m2 += f[k] * f[k];
+            s += sqrt(m2);
+        }
+        out[r] = s;
+    }
+    return 0;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

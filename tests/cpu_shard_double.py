@@ -1,0 +1,76 @@
+"""TEST DOUBLE (tests/ only): a CPU stand-in for HipShardBackend so the one-process-per-rank
+orchestration of nbody-simulation-parallel_amd/dist.py can be rehearsed over gloo without a GPU.
+It follows the device data flow exactly -- fp32 exchange buffer, own-chunk pass then remote pass,
+fp64 kick+drift refreshing the own chunk -- with numpy doing the pair sums in fp64."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class CpuShardDouble:
+    def __init__(self, bodies, layout):
+        self.layout = L = layout
+        d, pad = L.dim, L.shard_pad
+        self.pos_all = torch.zeros(L.pos_all_shape(), dtype=torch.float32)
+        self.mass_all = torch.zeros(L.mass_all_shape(), dtype=torch.float32)
+        for g in range(L.n_shards):
+            lo, hi = L.bounds(g)
+            self.pos_all[g, :, : hi - lo] = torch.from_numpy(bodies[lo:hi, :d].T.astype(np.float32))
+            self.mass_all[g, : hi - lo] = torch.from_numpy(bodies[lo:hi, -1].astype(np.float32))
+        lo, hi = L.bounds()
+        self.x = bodies[lo:hi, :d].copy()
+        self.v = bodies[lo:hi, d:2 * d].copy()
+        self.m = bodies[lo:hi, -1].copy()
+        self.acc = np.zeros((hi - lo, d))
+        self.calls = []
+
+    def _accel_from(self, chunks):
+        L = self.layout
+        tgt = self.pos_all[L.shard, :, : L.count].numpy().T.astype(np.float64)
+        out = np.zeros_like(tgt)
+        for g in chunks:
+            src = self.pos_all[g].numpy().T.astype(np.float64)
+            m = self.mass_all[g].numpy().astype(np.float64)
+            dvec = src[None, :, :] - tgt[:, None, :]
+            r2 = (dvec ** 2).sum(-1)
+            w = np.where(r2 < 1e-10, 0.0, m[None, :] / np.where(r2 < 1e-10, 1.0, r2) ** 2)
+            out += (w[:, :, None] * dvec).sum(1)
+        return out
+
+    def accel_local(self):
+        self.calls.append("local")
+        self.acc = self._accel_from([self.layout.shard])
+
+    def accel_remote(self):
+        self.calls.append("remote")
+        self.acc = self.acc + self._accel_from([g for g in range(self.layout.n_shards) if g != self.layout.shard])
+
+    def kick_drift(self, G, dt):
+        self.calls.append("kick_drift")
+        F = -((G * self.m)[:, None] * self.acc)
+        self.v += (F / self.m[:, None]) * dt
+        self.x += self.v * dt
+        self.pos_all[self.layout.shard, :, : self.layout.count] = torch.from_numpy(self.x.T.astype(np.float32))
+
+    def start_exchange(self, group):
+        self.calls.append("exchange")
+        if self.layout.n_shards == 1:
+            return None
+        return dist.all_gather_into_tensor(self.pos_all.view(-1), self.pos_all[self.layout.shard].reshape(-1).clone(),
+                                           group=group, async_op=True)
+
+    def finish_exchange(self, work):
+        if work is not None:
+            work.wait()
+
+    def forces(self, G):
+        return -((G * self.m)[:, None] * self.acc)
+
+    def download_into(self, bodies):
+        lo, hi = self.layout.bounds()
+        d = self.layout.dim
+        bodies[lo:hi, :d] = self.x
+        bodies[lo:hi, d:2 * d] = self.v
+
+    def synchronize(self):
+        pass

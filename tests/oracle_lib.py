@@ -78,6 +78,19 @@ class Oracle:
         assert rc == 0
         return out
 
+    def force_magnitude_sums(self, bodies, rows=None):
+        d = self._dim(bodies)
+        if rows is None:
+            out = np.zeros(bodies.shape[0])
+            rc = self.lib.oracle_force_magnitude_sums(_p(bodies), _sz(bodies.shape[0]), d, None, _sz(0), _p(out))
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            out = np.zeros(rows.size)
+            rc = self.lib.oracle_force_magnitude_sums(_p(bodies), _sz(bodies.shape[0]), d,
+                                                      rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _sz(rows.size), _p(out))
+        assert rc == 0
+        return out
+
     def update_body_velocities(self, bodies, forces, dt):
         assert forces.flags["C_CONTIGUOUS"] and forces.dtype == np.float64
         self.lib.oracle_update_body_velocities(_p(bodies), _p(forces), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(dt))
@@ -154,9 +167,50 @@ def have_reference() -> bool:
     return os.path.exists(REF_SO)
 
 
+# ---- the stated fp32 tolerance (DESIGN.md "Parity protocol") -------------------------------------
+# The device sums N fp32 pair terms; the oracle is the reference's fp64 sequential path fed the
+# same fp32-rounded inputs.  For body i let F_i be the oracle force, S_i = sum_j |f_ij| the sum of
+# pair-force magnitudes and kappa_i = S_i/|F_i| the condition number of the (cancelling) sum.
+#   (T1) |dF_i| <= TOL_BACKWARD * S_i            for EVERY body          (backward-stable sum)
+#   (T2) |dF_i| <= TOL_REL * |F_i|               for every body with kappa_i <= KAPPA_WELL
+# (T2) is BASELINE.json's "accelerations within 1e-5 relative"; bodies whose pair forces cancel to
+# less than 1/16 of their magnitude sum (about 2 % of uniform-random bodies; kappa reaches ~250 at
+# N=4096) cannot meet a plain relative bound in fp32 by construction -- they are held to (T1).
+# (T1)'s constant is the worst case of ONE fp32 pair term m*d/(r^2)^2: with unit roundoff
+# u = 2^-24 = 6e-8, d carries 1u, r^2 5u (entering squared: 10u), v_rcp_f32 1 ulp = 2u (squared:
+# 4u), three more products 3u  => 18u = 1.1e-6, plus the 256-term fp32 inner sums; measured maxima
+# are 1.0-1.7e-6 when one close neighbour dominates the sum.  2.5e-6 = 42u.
+TOL_REL = 1.0e-5
+TOL_BACKWARD = 2.5e-6
+KAPPA_WELL = 16.0
+
+
+def force_errors(forces, ref_forces, magnitude_sums):
+    """Returns dict(max_rel_well, max_rel_all, max_backward, n_ill, max_abs_accel is left to the caller)."""
+    dF = np.sqrt(((forces - ref_forces) ** 2).sum(axis=1))
+    nF = np.sqrt((ref_forces ** 2).sum(axis=1))
+    S = np.asarray(magnitude_sums)
+    live = S > 0
+    rel = np.where(nF > 0, dF / np.where(nF > 0, nF, 1.0), np.where(dF > 0, np.inf, 0.0))
+    kappa = np.where(nF > 0, S / np.where(nF > 0, nF, 1.0), np.inf)
+    well = live & (kappa <= KAPPA_WELL)
+    back = np.where(live, dF / np.where(live, S, 1.0), np.where(dF > 0, np.inf, 0.0))
+    return dict(max_rel_well=float(rel[well].max()) if well.any() else 0.0,
+                max_rel_all=float(rel[live].max()) if live.any() else 0.0,
+                max_backward=float(back.max()) if back.size else 0.0,
+                n_ill=int((live & ~well).sum()), n=int(live.sum()))
+
+
+def assert_force_parity(forces, ref_forces, magnitude_sums, what=""):
+    e = force_errors(forces, ref_forces, magnitude_sums)
+    assert np.isfinite(forces).all(), f"{what}: non-finite device forces"
+    assert e["max_backward"] <= TOL_BACKWARD, f"{what}: backward error {e['max_backward']:.3e} > {TOL_BACKWARD} ({e})"
+    assert e["max_rel_well"] <= TOL_REL, f"{what}: relative error {e['max_rel_well']:.3e} > {TOL_REL} on well-conditioned bodies ({e})"
+    return e
+
+
 def accel_errors(forces, ref_forces, masses, G):
-    """Accuracy protocol of SURVEY 8d: accelerations a = F/m; returns (max over bodies of
-    |da|_2/|a_ref|_2, max-abs component error of a)."""
+    """a = F/m; returns (max over bodies of |da|_2/|a_ref|_2, max-abs component error of a)."""
     a = forces / masses[:, None]
     r = ref_forces / masses[:, None]
     num = np.sqrt(((a - r) ** 2).sum(axis=1))
