@@ -29,7 +29,7 @@ $(CSRC)/force_kernel_slp.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
 $(CSRC)/force_kernel_scalar.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
 	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=scalar -fno-slp-vectorize -c $< -o $@
 
-$(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h
+$(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h Makefile
 	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -c $< -o $@
 
 # -ffp-contract=off: the fp64 kick/drift must round like the reference's two-step arithmetic
