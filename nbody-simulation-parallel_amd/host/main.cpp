@@ -1,0 +1,257 @@
+// main.cpp -- benchmark harness with the reference's command line, result files and CSV schema
+// (nbody-sim-new/main.cpp:18-875 run_benchmark, :877-951 main), rebuilt around a method table
+// instead of one copied block per method, with the MI355X row BruteForce_HIP added.
+//
+//   ./nbody_sim -N 100000 -d 3 -a 1            reference rows + BruteForce_HIP, accuracy column
+//   ./nbody_sim -N 1048576 -m g                HIP only (never gated by the 1e6-body CPU limit)
+//   ./nbody_sim -N 65536 -m g --steps 100 --dt 5   device-resident kick/drift loop
+//
+// Output: results/run_<MMDDYYYY_HHMMSS>_N_<n>_<D>D.{csv,out}; CSV "Method,Bodies,Dimension,Time(s)[,Accuracy(%)]"
+// with times fixed to 6 decimals (scientific below 1e-6), exactly the reference's format
+// (main.cpp:41-43, 59-63, 159-170), so run_simulations.sh and the analysis notebook read it unchanged.
+// The tree methods (b, h, f) are outside this build's scope: accepted on the command line, reported
+// as "not built", skipped.
+#include <functional>
+#include <iomanip>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "methods_cpu.h"
+#include "methods_hip.h"
+#include "utils_hip.h"
+
+namespace {
+
+struct Options {
+    int dimension = 3;
+    int num_bodies = 1000;
+    bool accuracy = false;
+    std::string methods;            // empty = everything that applies
+    bool override_bf_limit = false; // "-m a" alone lifts the 1e6-body gate (main.cpp:905-907)
+    long long seed = -1;            // -1: std::random_device like the reference
+    int steps = 0;                  // > 0: also run the leapfrog loop on the device
+    double dt = 1.0;
+    std::string init = "uniform";   // uniform | plummer
+    std::string dump;               // prefix: write bodies and each method's forces as raw doubles
+};
+
+template <typename T>
+void dump_raw(const std::string& path, const std::vector<T>& v) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(T)));
+}
+
+// tee to log file and stdout, as every message of the reference harness is
+struct Tee {
+    std::ofstream& log;
+    template <typename T>
+    Tee& operator<<(const T& v) { log << v; std::cout << v; return *this; }
+    Tee& operator<<(std::ostream& (*manip)(std::ostream&)) { manip(log); manip(std::cout); return *this; }
+};
+
+void write_time(std::ostream& csv, double seconds) {
+    if (seconds < 1e-6) csv << "," << std::scientific << std::setprecision(6) << seconds;
+    else csv << "," << std::fixed << std::setprecision(6) << seconds;
+}
+
+template <int D>
+void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id, const Options& opt) {
+    using Forces = std::vector<Vector<D>>;
+    const int n = static_cast<int>(bodies.size());
+    const std::string& m = opt.methods;
+    const bool want_a = m.empty() || m.find('a') != std::string::npos;
+    const bool run_cpu_bf = want_a && (n <= 1000000 || opt.override_bf_limit);  // main.cpp:24
+    const bool run_hip = want_a || m.find('g') != std::string::npos;            // never size-gated
+    const bool asked_tree = m.empty() || m.find_first_of("bhf") != std::string::npos;
+
+    ensure_results_directory();
+    const std::string base = "results/run_" + run_id + "_N_" + std::to_string(n) + "_" + std::to_string(D) + "D";
+    std::ofstream csv(base + ".csv"), log(base + ".out"), hipcsv;
+    if (!csv.is_open() || !log.is_open()) {
+        std::cerr << "Failed to open output files: " << base << ".{csv,out}" << std::endl;
+        return;
+    }
+    Tee out{log};
+    if (!opt.dump.empty()) dump_raw(opt.dump + "_bodies.f64", bodies);
+    csv << "Method,Bodies,Dimension,Time(s)" << (opt.accuracy ? ",Accuracy(%)" : "") << std::endl;
+
+    out << "Running N-body simulation benchmark with:" << std::endl
+        << "  Dimension: " << D << "D" << std::endl
+        << "  Bodies: " << n << std::endl
+        << "  Run ID: " << run_id << std::endl;
+    if (opt.accuracy) out << "  Accuracy calculation: ON" << std::endl;
+    out << "  Methods: " << (run_cpu_bf ? "Brute Force " : "") << (run_hip ? "Brute Force (HIP) " : "") << std::endl;
+    if (asked_tree && !m.empty()) out << "  (Barnes-Hut / BVH / FMM are not built in this tier: skipped)" << std::endl;
+    out << std::endl;
+
+    // accuracy reference: sequential below 1e5 bodies, OpenMP all-to-all above (main.cpp:102-124)
+    Forces reference;
+    if (opt.accuracy) {
+        const bool seq = n < 100000;
+        out << "Using brute force " << (seq ? "sequential" : "OpenMP") << " as reference for accuracy calculation..." << std::endl;
+        reference = seq ? brute_force_seq_n_body<D>(bodies) : brute_force_omp_n_body_2<D>(bodies);
+    } else {
+        out << "Accuracy calculation disabled." << std::endl;
+    }
+
+    struct Method {
+        const char* label;       // CSV name
+        const char* banner;      // heading printed before the run
+        bool threaded;           // print "Using <k> threads..."
+        bool enabled;
+        std::function<Forces()> solve;
+    };
+    const std::vector<Method> table = {
+        {"BruteForce_Sequential", "Brute force O(n²) sequential approach:", false, run_cpu_bf,
+         [&] { return brute_force_seq_n_body<D>(bodies); }},
+        {"BruteForce_OpenMP1", "Brute force OpenMP parallel approach (memory-intensive):", true, run_cpu_bf,
+         [&] { return brute_force_omp_n_body_1<D>(bodies); }},
+        {"BruteForce_OpenMP2", "Brute force OpenMP parallel approach (memory-efficient):", true, run_cpu_bf,
+         [&] { return brute_force_omp_n_body_2<D>(bodies); }},
+        {"BruteForce_HIP", "Brute force HIP (MI355X, fp32 tiled all-pairs) approach:", false, run_hip,
+         [&] { return brute_force_hip_n_body<D>(bodies); }},
+    };
+
+    for (const Method& method : table) {
+        if (!method.enabled) continue;
+        out << method.banner << std::endl;
+        if (method.threaded) out << "Using " << omp_get_max_threads() << " threads..." << std::endl;
+        Forces forces;
+        const long long us = safely_execute(log, method.label, [&] { forces = method.solve(); return 0; });
+        if (us >= 0) {
+            const double seconds = static_cast<double>(us) / 1e6;
+            double accuracy = -1.0;
+            if (opt.accuracy) accuracy = compute_accuracy<D>(forces, reference);
+            csv << method.label << "," << n << "," << D;
+            write_time(csv, seconds);
+            if (opt.accuracy) csv << "," << std::fixed << std::setprecision(2) << accuracy;
+            csv << std::endl;
+            out << "Time taken: " << seconds << " s" << std::endl;
+            if (opt.accuracy) out << "Accuracy: " << std::to_string(accuracy) << "%" << std::endl;
+            if (std::string(method.label) == "BruteForce_HIP") {
+                const double kernel_s = last_hip_run_info().kernel_ms * 1e-3;
+                const double pairs = static_cast<double>(n) * static_cast<double>(n);
+                out << "Kernel time: " << kernel_s << " s  (" << pairs / kernel_s << " pair-interactions/s, "
+                    << 100.0 * pairs * 20.0 / kernel_s / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
+                hipcsv.open(base + "_hip.csv");
+                hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec" << std::endl
+                       << method.label << "," << n << "," << D << "," << std::fixed << std::setprecision(6) << seconds << ","
+                       << kernel_s << "," << std::scientific << pairs / kernel_s << std::endl;
+            }
+            print_validation_forces<D>(forces, n, log);
+            print_validation_forces<D>(forces, n, std::cout);
+            if (!opt.dump.empty()) dump_raw(opt.dump + "_" + method.label + ".f64", forces);
+        }
+        out << std::endl;
+    }
+
+    if (opt.steps > 0 && run_hip) {
+        out << "Leapfrog (kick-drift) on HIP: " << opt.steps << " steps, dt = " << opt.dt << std::endl;
+        std::vector<Body<D>> state = bodies;
+        const long long us = safely_execute(log, "Leapfrog_HIP", [&] { leapfrog_hip_n_body<D>(state, opt.dt, opt.steps); return 0; });
+        if (us >= 0) {
+            const double seconds = static_cast<double>(us) / 1e6;
+            csv << "Leapfrog_HIP_" << opt.steps << "steps," << n << "," << D;
+            write_time(csv, seconds);
+            if (opt.accuracy) csv << ",";
+            csv << std::endl;
+            const double kernel_s = last_hip_run_info().kernel_ms * 1e-3;
+            out << "Time taken: " << seconds << " s (" << seconds / opt.steps << " s/step; force kernels " << kernel_s << " s, "
+                << static_cast<double>(n) * n * opt.steps / kernel_s << " pair-interactions/s)" << std::endl;
+            if (!opt.dump.empty()) dump_raw(opt.dump + "_Leapfrog_HIP.f64", state);
+            out << "Body #1 position: (";
+            for (int d = 0; d < D; ++d) out << state[0].position[d] << (d < D - 1 ? ", " : "");
+            out << ")" << std::endl;
+        }
+        out << std::endl;
+    }
+}
+
+void usage(const char* argv0) {
+    std::cout << "Usage: " << argv0 << " [options]" << std::endl
+              << "Options:" << std::endl
+              << "  -d, --dim <2|3>     Set simulation dimension (default: 3)" << std::endl
+              << "  -N, --bodies <num>  Set number of bodies (default: 1000)" << std::endl
+              << "  -a, --accuracy <0|1> Enable accuracy calculation (default: 0 - OFF)" << std::endl
+              << "  -m, --methods <str> Specify which methods to run (default: all)" << std::endl
+              << "                      a=bruteforce (CPU rows + HIP), g=HIP brute force only," << std::endl
+              << "                      b=barnes-hut, h=hilbert bvh, f=fmm (not built in this tier)" << std::endl
+              << "      --seed <int>    Reproducible bodies (default: random_device, like the reference)" << std::endl
+              << "      --init <uniform|plummer>  Initial condition (default: uniform)" << std::endl
+              << "      --steps <k>     Also run k kick-drift steps on the device" << std::endl
+              << "      --dt <t>        Time step for --steps (default: 1)" << std::endl
+              << "      --dump <prefix> Write bodies and every method's forces as raw doubles (<prefix>_<Method>.f64)" << std::endl
+              << "  -h, --help          Display this help message" << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    Options opt;
+    for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        const bool has_value = i + 1 < argc;
+        if ((arg == "-d" || arg == "--dim") && has_value) {
+            opt.dimension = std::stoi(argv[++i]);
+            if (opt.dimension != 2 && opt.dimension != 3) {
+                std::cerr << "Error: Dimension must be either 2 or 3" << std::endl;
+                return 1;
+            }
+        } else if ((arg == "-N" || arg == "--bodies") && has_value) {
+            opt.num_bodies = std::stoi(argv[++i]);
+            if (opt.num_bodies <= 0) {
+                std::cerr << "Error: Number of bodies must be positive" << std::endl;
+                return 1;
+            }
+        } else if ((arg == "-a" || arg == "--accuracy") && has_value) {
+            opt.accuracy = std::stoi(argv[++i]) == 1;
+        } else if ((arg == "-m" || arg == "--methods") && has_value) {
+            opt.methods = argv[++i];
+            opt.override_bf_limit = opt.methods == "a";
+            for (char c : opt.methods)
+                if (std::string("abhfg").find(c) == std::string::npos) {
+                    std::cerr << "Error: Invalid method '" << c << "'" << std::endl
+                              << "Valid methods: a=bruteforce, g=hip bruteforce, b=barnes-hut, h=bvh, f=fmm" << std::endl;
+                    return 1;
+                }
+        } else if (arg == "--seed" && has_value) {
+            opt.seed = std::stoll(argv[++i]);
+        } else if (arg == "--steps" && has_value) {
+            opt.steps = std::stoi(argv[++i]);
+        } else if (arg == "--dt" && has_value) {
+            opt.dt = std::stod(argv[++i]);
+        } else if (arg == "--dump" && has_value) {
+            opt.dump = argv[++i];
+        } else if (arg == "--init" && has_value) {
+            opt.init = argv[++i];
+            if (opt.init != "uniform" && opt.init != "plummer") {
+                std::cerr << "Error: --init must be uniform or plummer" << std::endl;
+                return 1;
+            }
+        } else if (arg == "-h" || arg == "--help") {
+            usage(argv[0]);
+            return 0;
+        }
+    }
+
+    const std::string run_id = get_run_id();
+    try {
+        if (opt.dimension == 2) {
+            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<2>(opt.num_bodies, opt.seed)
+                                                : generate_random_bodies<2>(opt.num_bodies, opt.seed);
+            run_benchmark<2>(bodies, run_id, opt);
+        } else {
+            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<3>(opt.num_bodies, opt.seed)
+                                                : generate_random_bodies<3>(opt.num_bodies, opt.seed);
+            run_benchmark<3>(bodies, run_id, opt);
+        }
+    } catch (const std::exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 1;
+    } catch (...) {
+        std::cerr << "Unknown error occurred" << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,55 @@
+// methods_hip.cpp -- thin C++ shim from the reference-shaped templates onto the C ABI.
+#include "methods_hip.h"
+
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#include "nbody_hip.h"
+
+namespace {
+thread_local HipRunInfo g_info;
+int g_device = -1;
+
+int device_ordinal() {
+    if (g_device >= 0) return g_device;
+    if (const char* e = std::getenv("NBODY_HIP_DEVICE")) return std::atoi(e);
+    return 0;
+}
+
+[[noreturn]] void raise(const char* where, int status) {
+    std::string msg = std::string(where) + ": " + nbx_strerror(status);
+    const char* detail = nbx_last_error_detail();
+    if (detail && *detail) msg += std::string(" -- ") + detail;
+    throw std::runtime_error(msg);
+}
+}  // namespace
+
+const HipRunInfo& last_hip_run_info() { return g_info; }
+void set_hip_device(int device) { g_device = device; }
+
+template <int D>
+std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies) {
+    std::vector<Vector<D>> forces(bodies.size());
+    g_info = HipRunInfo{};
+    g_info.device = device_ordinal();
+    const int rc = nbx_brute_force_forces(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G,
+                                          g_info.device, reinterpret_cast<double*>(forces.data()), &g_info.kernel_ms);
+    if (rc != NBX_OK) raise("brute_force_hip_n_body", rc);
+    return forces;
+}
+
+template <int D>
+void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps) {
+    g_info = HipRunInfo{};
+    g_info.device = device_ordinal();
+    const int rc = nbx_leapfrog(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G, dt, nsteps,
+                                g_info.device, &g_info.kernel_ms);
+    if (rc != NBX_OK) raise("leapfrog_hip_n_body", rc);
+}
+
+// explicit instantiations, like nbody-sim-new/methods.cpp:452-499 does for the CPU solvers
+template std::vector<Vector<2>> brute_force_hip_n_body<2>(const std::vector<Body<2>>&);
+template std::vector<Vector<3>> brute_force_hip_n_body<3>(const std::vector<Body<3>>&);
+template void leapfrog_hip_n_body<2>(std::vector<Body<2>>&, double, int);
+template void leapfrog_hip_n_body<3>(std::vector<Body<3>>&, double, int);

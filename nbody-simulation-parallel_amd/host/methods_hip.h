@@ -1,0 +1,38 @@
+// methods_hip.h -- solver entry points with the reference's methods.h shape, backed by the MI355X
+// HIP library through its C ABI (include/nbody_hip.h).  Drop-in for nbody-sim-new/methods.h:29-37
+// and :85-91: include it next to (or instead of) methods.h, compile methods_hip.cpp with the
+// reference's flags, link -lnbody_hip, and add one harness block.
+//
+// It only needs `Body<D>` / `Vector<D>` with the reference's memory layout: this repository's
+// body.h / vector.h, or the reference's own when built inside the reference tree.
+#ifndef NBODY_AMD_METHODS_HIP_H
+#define NBODY_AMD_METHODS_HIP_H
+
+#include <vector>
+
+#include "body.h"
+#include "vector.h"
+
+// Same contract as brute_force_seq_n_body<D> / brute_force_omp_n_body_{1,2}<D>: forces (not
+// accelerations) on every body under the reference's law, F_i = -G m_i sum_j m_j (p_j-p_i)/r^4 with
+// pairs of r^2 < 1e-10 skipped.  Throws std::runtime_error on any device failure (the harness's
+// safely_execute, utils.h:95-103, then logs it and skips the row); there is no CPU fallback.
+template <int D>
+std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies);
+
+// nsteps x { forces; update_body_velocities(bodies, forces, dt); update_body_positions(bodies, dt); }
+// (methods.cpp:425-450) with the state resident on the device between steps.
+template <int D>
+void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps);
+
+// Timing of the most recent call on this thread, for pair-interactions/s and roofline reporting.
+struct HipRunInfo {
+    float kernel_ms = 0.0f;   // force-kernel time only (hipEvent), summed over the call's launches
+    int device = 0;
+};
+const HipRunInfo& last_hip_run_info();
+
+// Device ordinal used by the two entry points above (default 0; NBODY_HIP_DEVICE overrides).
+void set_hip_device(int device);
+
+#endif  // NBODY_AMD_METHODS_HIP_H

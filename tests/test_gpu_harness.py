@@ -1,0 +1,52 @@
+"""GPU: the C++ drop-in (host/methods_hip.cpp over the C ABI) through the harness binary: the
+BruteForce_HIP row sits next to the reference's CPU rows in the same CSV, reads 100 % on the
+reference's own accuracy metric, and its forces meet the stated fp32 tolerance against the oracle."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_lib import assert_force_parity
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "nbody_sim")
+
+
+def _run(tmp_path, *args):
+    assert os.path.exists(EXE), "nbody_sim must be built in-tree (make nbody_sim) before the GPU run"
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    return subprocess.run([EXE, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+def test_hip_row_in_reference_csv(tmp_path, oracle, dim):
+    n, seed = 4096, 2
+    p = _run(tmp_path, "-N", str(n), "-d", str(dim), "-a", "1", "--seed", str(seed), "--dump", "d")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    csv = glob.glob(os.path.join(tmp_path, "results", f"run_*_N_{n}_{dim}D.csv"))[0]
+    rows = [l.split(",") for l in open(csv).read().strip().splitlines()[1:]]
+    assert [r[0] for r in rows] == ["BruteForce_Sequential", "BruteForce_OpenMP1", "BruteForce_OpenMP2", "BruteForce_HIP"]
+    assert rows[3][4] == "100.00"
+    assert os.path.exists(csv[:-4] + "_hip.csv")
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 2 * dim + 1)
+    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, dim)
+    br = oracle.round_inputs_to_f32(bodies)
+    assert_force_parity(f, oracle.brute_force_seq(br), oracle.force_magnitude_sums(br), f"harness D={dim}")
+
+
+def test_hip_only_large_n_and_leapfrog(tmp_path, oracle):
+    n = 1 << 17   # above nothing the CPU rows would run quickly; -m g skips them
+    p = _run(tmp_path, "-N", str(n), "-m", "g", "--seed", "4", "--steps", "3", "--dt", "2.5", "--dump", "d")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    assert "pair-interactions/s" in p.stdout
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
+    state = np.fromfile(os.path.join(tmp_path, "d_Leapfrog_HIP.f64")).reshape(n, 7)
+    assert np.allclose(state[:, :3], bodies[:, :3] + bodies[:, 3:6] * 7.5, rtol=1e-12, atol=0)
+    assert np.array_equal(state[:, 6], bodies[:, 6])
+    rows = np.arange(0, n, n // 64)
+    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
+    br = oracle.round_inputs_to_f32(bodies)
+    assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "harness sampled rows")
