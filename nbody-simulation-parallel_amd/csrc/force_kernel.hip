@@ -43,7 +43,11 @@ namespace nbx {
 namespace NBX_FLAVOUR {
 namespace {
 
-enum Guard { GUARD_EXACT = 0, GUARD_CLAMP = 1 };
+enum Guard { GUARD_EXACT = 0, GUARD_CLAMP = 1, GUARD_TINY = 2 };
+
+// GUARD_TINY: r^2 is biased by kTiny so that rcp stays finite for coincident bodies (d = 0 => the
+// term is exactly 0) -- no compare, no select.  Exact only if no pair has 0 < r^2 < ~1e-8.
+constexpr float kTiny = 1.0e-15f;
 
 // One pair interaction.  s{xyz,m} is wave-uniform (LDS broadcast or SGPR), i{xyz} per lane.
 template <int D, int GUARD>
@@ -52,7 +56,7 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
                                          float& ax, float& ay, float& az) {
     const float dx = sx - ix;
     const float dy = sy - iy;
-    float r2 = dx * dx;
+    float r2 = (GUARD == GUARD_TINY) ? __builtin_fmaf(dx, dx, kTiny) : dx * dx;
     r2 = __builtin_fmaf(dy, dy, r2);
     float dz = 0.0f;
     if (D == 3) {
@@ -62,6 +66,7 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
     // methods.cpp:24 -- `if (dist_sq < 1e-10) continue;`  rcp(+inf) = +0 makes the pair's weight 0.
     float r2g;
     if (GUARD == GUARD_EXACT) r2g = (r2 < kR2SkipF) ? __builtin_inff() : r2;
+    else if (GUARD == GUARD_TINY) r2g = r2;
     else r2g = __builtin_fmaxf(r2, kR2SkipF);  // experimental: exact only if no pair has 0 < r2 < 1e-10
     const float ri2 = __builtin_amdgcn_rcpf(r2g);  // v_rcp_f32, 1 ulp
     const float t = sm * ri2;
@@ -263,6 +268,12 @@ const KernelVariant kVariants[] = {
     {NBX_NAME("smem_t2_w4_exact_b16"), 2, NBX_SMEM(2, 4, GUARD_EXACT, 16)},
     {NBX_NAME("smem_t4_w4_exact_b8"), 4, NBX_SMEM(4, 4, GUARD_EXACT, 8)},
     {NBX_NAME("lds_t2_w8_clamp_u8"), 2, NBX_LDS(2, 8, GUARD_CLAMP, 8)},    // experimental guard
+    {NBX_NAME("lds_t1_w8_tiny_u8"), 1, NBX_LDS(1, 8, GUARD_TINY, 8)},      // experimental guard
+    {NBX_NAME("lds_t2_w8_tiny_u8"), 2, NBX_LDS(2, 8, GUARD_TINY, 8)},      // experimental guard
+    {NBX_NAME("lds_t4_w4_tiny_u4"), 4, NBX_LDS(4, 4, GUARD_TINY, 4)},      // experimental guard
+    {NBX_NAME("lds_t4_w4_tiny_u8"), 4, NBX_LDS(4, 4, GUARD_TINY, 8)},      // experimental guard
+    {NBX_NAME("smem_t2_w8_tiny_b8"), 2, NBX_SMEM(2, 8, GUARD_TINY, 8)},    // experimental guard
+    {NBX_NAME("smem_t4_w4_tiny_b8"), 4, NBX_SMEM(4, 4, GUARD_TINY, 8)},    // experimental guard
     {NBX_NAME("smem_t2_w8_clamp_b8"), 2, NBX_SMEM(2, 8, GUARD_CLAMP, 8)},  // experimental guard
 };
 

@@ -1,0 +1,29 @@
+"""Interleaved A/B timing of force-kernel variants in one process (guide rule 24).
+   python tools/time_variants.py [N] [rounds] [name-substring ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import nbody_amd as nbx
+from oracle_lib import Oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+pats = sys.argv[3:]
+names = nbx.variants()
+sel = [i for i, nm in enumerate(names) if not pats or any(p in nm for p in pats)]
+o = Oracle()
+b = o.generate(1, n, 3)
+with nbx.Context(n, 3) as c:
+    c.upload(b)
+    res = {v: [] for v in sel}
+    for r in range(rounds + 1):
+        for v in sel:
+            c.set_tuning(0, v)
+            c.compute_accel()
+            ms, _ = c.kernel_time()
+            if r: res[v].append(ms)
+    print(f"N={n}  interactions {n*n:.3e}  rounds {rounds}", flush=True)
+    for v in sorted(sel, key=lambda v: min(res[v])):
+        best, med = min(res[v]), sorted(res[v])[len(res[v]) // 2]
+        print(f"{names[v]:30s} best {best:9.3f} ms  median {med:9.3f} ms  {n*n/best*1e3/1e12:6.3f} T-pairs/s  {n*n/best*1e3*20/157.3e12*100:5.1f}% of fp32 peak", flush=True)
