@@ -20,17 +20,19 @@ lib: $(LIB)
 OBJS := $(CSRC)/force_kernel_slp.o $(CSRC)/force_kernel_scalar.o $(CSRC)/force_launch.o \
         $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o
 # name of the force-kernel variant used when the caller does not pick one
-DEFAULT_VARIANT ?= lds_t1_w8_exact_u8_scalar
+DEFAULT_VARIANT ?= fastpks_t8_w4_u4_scalar
+# exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
+DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8_scalar
 
 # the force kernel is built in two code-generation flavours (see force_kernel.hip)
 $(CSRC)/force_kernel_slp.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
 	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=slp -c $< -o $@
 
 $(CSRC)/force_kernel_scalar.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
-	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=scalar -fno-slp-vectorize -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=scalar -DNBX_EMIT_CLOSE_KERNELS -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h Makefile
-	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -DNBX_DEFAULT_EXACT_VARIANT='"$(DEFAULT_EXACT_VARIANT)"' -c $< -o $@
 
 # -ffp-contract=off: the fp64 kick/drift must round like the reference's two-step arithmetic
 $(CSRC)/state_kernels.o: $(CSRC)/state_kernels.hip $(CSRC)/nbx_internal.h

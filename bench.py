@@ -140,8 +140,7 @@ def main():
         launches_per_step = 1 if world == 1 else 2
         kern_s_per_step = kern_ms * 1e-3 * launches_per_step
         achieved_tflops = my_pairs_per_launch * FLOP_PER_INTERACTION / kern_s_per_step / 1e12
-        lib = nbx.load_library()
-        vid = args.variant if args.variant >= 0 else lib.nbx_default_variant()
+        variant_name, source_splits = be.ctx.effective_tuning()
         result = {
             "metric": "body-pair interactions/sec at N=2^20 (all-pairs force + kick/drift step)" if N == 1 << 20
                       else f"body-pair interactions/sec at N={N}",
@@ -150,11 +149,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"N={N} {args.dim}D uniform-random bodies (reference generator ranges, seed {args.seed}), "
                                    "one all-pairs force evaluation + fused kick/drift per step",
-                       "n_bodies": N, "dim": args.dim, "lds_tile": 256, "kernel_variant": lib.nbx_variant_name(vid).decode(),
+                       "n_bodies": N, "dim": args.dim, "lds_tile": 256, "kernel_variant": variant_name, "source_slices": source_splits,
                        "parallelism": "1 GPU" if world == 1 else f"{world} target shards, RCCL all-gather of positions per step"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "accel_lds_kernel/accel_smem_kernel (force)", "kernel_ms_mean": kern_ms,
+                         "kernel": "nbx force kernel, variant " + variant_name, "kernel_ms_mean": kern_ms,
                          "kernel_launches_timed": launches, "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": my_pairs_per_launch / launches_per_step,
                          "note": "binding roofline is fp32 VALU issue (no MFMA, HBM-light); peak = MI355X fp32 vector = fp32 matrix peak",

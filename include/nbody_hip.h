@@ -97,7 +97,7 @@ int nbx_ctx_set_gather_buffers(nbx_ctx* ctx, void* pos_all_f32, void* mass_all_f
 /* Layout of the exchange buffers:
  *   pos_all : float[n_shards][dim][shard_pad]   -- chunk g = shard g's x[], y[], (z[]) arrays
  *   mass_all: float[n_shards][shard_pad]
- * shard_len = bodies per shard, shard_pad = shard_len rounded up to the source tile (256); pad
+ * shard_len = bodies per shard, shard_pad = shard_len rounded up to a multiple of 4096 bodies; pad
  * entries are massless bodies at the origin (they contribute exactly zero).
  * Any out pointer may be NULL. */
 int nbx_ctx_gather_layout(const nbx_ctx* ctx, size_t* shard_len, size_t* shard_pad,
@@ -133,10 +133,16 @@ int nbx_ctx_download_bodies(nbx_ctx* ctx, void* bodies, size_t body_stride_bytes
 
 int nbx_ctx_synchronize(nbx_ctx* ctx);
 
-/* Tuning knobs.  source_splits: number of slices the source loop is cut into (0 = automatic; more
- * workgroups for small shards; partial sums are combined in a fixed order).  variant: force-kernel
- * variant id in [0, nbx_num_variants()), -1 = library default (see DESIGN.md for the table). */
+/* Tuning knobs.  source_splits: number of slices the source loop is cut into (0 = automatic, else a
+ * lower bound in [1,256]; more workgroups for small shards; partial sums are combined in a fixed
+ * order).  variant: force-kernel variant id in [0, nbx_num_variants()), -1 = library default (see
+ * DESIGN.md for the table).  "fast" variants drop the per-pair r^2 guard and evaluate the few targets
+ * that could own a sub-threshold pair with the guarded kernel, so the result keeps the reference's
+ * skip semantics; when their preconditions fail (a mass above 1e10, or most of the shard within
+ * 8192 of a coordinate plane) the library substitutes the guarded default. */
 int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
+/* The variant and slice count the next force evaluation will use (after upload). */
+int nbx_ctx_effective_tuning(nbx_ctx* ctx, int* variant, int* source_splits);
 int nbx_num_variants(void);
 const char* nbx_variant_name(int variant);
 int nbx_default_variant(void);

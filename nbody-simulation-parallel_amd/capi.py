@@ -48,6 +48,7 @@ ABI = [
     ("nbx_ctx_download_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_ctx_synchronize", _i, [_vp]),
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
+    ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
     ("nbx_num_variants", _i, []),
     ("nbx_variant_name", _c.c_char_p, [_i]),
     ("nbx_default_variant", _i, []),
@@ -191,6 +192,11 @@ class Context:
 
     def set_tuning(self, source_splits: int = 0, variant: int = -1):
         self._ck(self.lib.nbx_ctx_set_tuning(self.h, source_splits, variant), "nbx_ctx_set_tuning")
+
+    def effective_tuning(self) -> Tuple[str, int]:
+        v, s = ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(self.lib.nbx_ctx_effective_tuning(self.h, ctypes.byref(v), ctypes.byref(s)), "nbx_ctx_effective_tuning")
+        return self.lib.nbx_variant_name(v.value).decode(), s.value
 
     def upload(self, bodies: np.ndarray):
         b, dim = _as_bodies(bodies)

@@ -1,4 +1,4 @@
-// force_kernel.hip -- K1/K2: tiled all-pairs accumulate kernel for gfx950 (MI355X), fp32, D = 2 or 3.
+// force_kernel.hip -- K1/K2: tiled all-pairs accumulate kernels for gfx950 (MI355X), fp32, D = 2 or 3.
 //
 // Computes, for every target i of one shard,
 //     a_i = sum_j  m_j * (p_j - p_i) / r_ij^4 ,   pairs with r_ij^2 < 1e-10 contribute exactly 0,
@@ -12,25 +12,25 @@
 //     tile, double-buffered: one s_barrier per tile); every lane reads the same LDS address, so a
 //     single ds_read_b128 broadcast feeds 64*TPL pair interactions -- or (SMEM variants) sources
 //     arrive through the scalar cache as SGPR operands and cost no vector or LDS instruction;
-//   * per pair 14 VALU instructions, all plain fp32 (v_sub x3, v_mul, v_fma x2, v_cmp+v_cndmask,
-//     v_rcp, v_mul x2, v_fma x3); packed fp32 buys nothing on gfx950 (measured: v_pk_fma_f32 issues
-//     at half the v_fma_f32 rate -- profiles/ubench_valu_r1.txt) and MFMA does not apply (no
-//     contraction: the kernel is an element-wise map with a reciprocal in the middle);
-//   * two-level summation: fp32 partial sums over one 256-source tile are flushed into an fp64
-//     second-level accumulator (3 v_add_f64 per 256 pairs per target: free), which keeps the error
-//     at the level of the 256-term inner sums whatever N is (a naive fp32 running sum: ~3e-4 at
-//     N = 131,072; an fp32 second level: 1.6e-6 of the magnitude sum at N = 2^20, measured).
-//   * grid = (target blocks, source slices): small shards are cut along the source list so the
-//     launch still covers all 1024 SIMDs; slice results land in acc[slice] and are summed in a
-//     fixed order by the consumer kernels (deterministic, no atomics).
+//   * exact kernels: 14 VALU per pair (v_sub x3, v_mul, v_fma x2, v_cmp+v_cndmask, v_rcp, v_mul x2,
+//     v_fma x3).  Fast kernels: targets are held as float2 pairs and the arithmetic is written on
+//     2-vectors (v_pk_add/mul/fma_f32: 12-25 % cheaper per element than the scalar forms on gfx950,
+//     tools/ubench_valu.hip), and the per-pair guard is replaced by the close-set pipeline described
+//     in nbx_internal.h: 11 v_pk + 2 v_rcp per TWO pairs.  MFMA does not apply (no contraction).
+//   * two-level summation: fp32 partial sums over one 256-source tile are flushed into second-level
+//     accumulators -- fp64 in the exact kernels, fp32 over at most 256 tiles (one source slice) in
+//     the fast kernels, whose slices are then summed in fp64 by the consumers.
+//   * grid = (target blocks, source slices): slices cut the source-tile list so that small shards
+//     still cover all 1024 SIMDs; slice results land in acc[slice] and are summed in a fixed order
+//     by the consumer kernels (deterministic, no atomics).
 #include "nbx_internal.h"
 
 #include <climits>
 #include <cmath>
 
 // This file is compiled twice (Makefile): NBX_FLAVOUR=slp with hipcc's defaults (the SLP vectoriser
-// pairs the TPL>=2 arithmetic into v_pk_*_f32) and NBX_FLAVOUR=scalar with -fno-slp-vectorize (plain
-// v_*_f32 only).  Both flavours sit in one library so they can be A/B-timed in one process.
+// pairs the TPL>=2 arithmetic of the scalar-source kernels into v_pk_*_f32) and NBX_FLAVOUR=scalar
+// with -fno-slp-vectorize.  Both flavours sit in one library so they can be A/B-timed in one process.
 #ifndef NBX_FLAVOUR
 #define NBX_FLAVOUR slp
 #endif
@@ -43,11 +43,9 @@ namespace nbx {
 namespace NBX_FLAVOUR {
 namespace {
 
-enum Guard { GUARD_EXACT = 0, GUARD_CLAMP = 1, GUARD_TINY = 2 };
+enum Guard { GUARD_EXACT = 0, GUARD_TINY = 2 };
 
-// GUARD_TINY: r^2 is biased by kTiny so that rcp stays finite for coincident bodies (d = 0 => the
-// term is exactly 0) -- no compare, no select.  Exact only if no pair has 0 < r^2 < ~1e-8.
-constexpr float kTiny = 1.0e-15f;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // One pair interaction.  s{xyz,m} is wave-uniform (LDS broadcast or SGPR), i{xyz} per lane.
 template <int D, int GUARD>
@@ -64,16 +62,86 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
         r2 = __builtin_fmaf(dz, dz, r2);
     }
     // methods.cpp:24 -- `if (dist_sq < 1e-10) continue;`  rcp(+inf) = +0 makes the pair's weight 0.
-    float r2g;
-    if (GUARD == GUARD_EXACT) r2g = (r2 < kR2SkipF) ? __builtin_inff() : r2;
-    else if (GUARD == GUARD_TINY) r2g = r2;
-    else r2g = __builtin_fmaxf(r2, kR2SkipF);  // experimental: exact only if no pair has 0 < r2 < 1e-10
+    const float r2g = (GUARD == GUARD_EXACT) ? ((r2 < kR2SkipF) ? __builtin_inff() : r2) : r2;
     const float ri2 = __builtin_amdgcn_rcpf(r2g);  // v_rcp_f32, 1 ulp
     const float t = sm * ri2;
     const float s = t * ri2;  // m_j / r^4
     ax = __builtin_fmaf(s, dx, ax);
     ay = __builtin_fmaf(s, dy, ay);
     if (D == 3) az = __builtin_fmaf(s, dz, az);
+}
+
+// The same for a PAIR of targets held in the two halves of 64-bit registers.
+template <int D, int GUARD>
+__device__ __forceinline__ void interact2(float sx, float sy, float sz, float sm, f2 ix, f2 iy, f2 iz,
+                                          f2& ax, f2& ay, f2& az) {
+    const f2 dx = f2{sx, sx} - ix;
+    const f2 dy = f2{sy, sy} - iy;
+    f2 r2 = (GUARD == GUARD_TINY) ? __builtin_elementwise_fma(dx, dx, f2{kTiny, kTiny}) : dx * dx;
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    f2 dz = f2{0.f, 0.f};
+    if (D == 3) {
+        dz = f2{sz, sz} - iz;
+        r2 = __builtin_elementwise_fma(dz, dz, r2);
+    }
+    if (GUARD == GUARD_EXACT) {
+        r2.x = (r2.x < kR2SkipF) ? __builtin_inff() : r2.x;
+        r2.y = (r2.y < kR2SkipF) ? __builtin_inff() : r2.y;
+    }
+    f2 w;
+    w.x = __builtin_amdgcn_rcpf(r2.x);
+    w.y = __builtin_amdgcn_rcpf(r2.y);
+    const f2 t = f2{sm, sm} * w;
+    const f2 s = t * w;
+    ax = __builtin_elementwise_fma(s, dx, ax);
+    ay = __builtin_elementwise_fma(s, dy, ay);
+    if (D == 3) az = __builtin_elementwise_fma(s, dz, az);
+}
+
+// The same for PAIRS target pairs at once, written stage by stage so that the PAIRS dependency chains
+// are interleaved in program order (each v_pk result is consumed PAIRS instructions later).
+template <int D, int PAIRS>
+__device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, float sm, const f2 (&ix)[PAIRS],
+                                                 const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
+                                                 f2 (&ay)[PAIRS], f2 (&az)[PAIRS]) {
+    f2 dx[PAIRS], dy[PAIRS], dz[PAIRS], r2[PAIRS], w[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) dx[q] = f2{sx, sx} - ix[q];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) dy[q] = f2{sy, sy} - iy[q];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) dz[q] = (D == 3) ? f2{sz, sz} - iz[q] : f2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dx[q], dx[q], f2{kTiny, kTiny});
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dy[q], dy[q], r2[q]);
+    if (D == 3) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dz[q], dz[q], r2[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) r2[q] = f2{sm, sm} * w[q];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) w[q] = r2[q] * w[q];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) ax[q] = __builtin_elementwise_fma(w[q], dx[q], ax[q]);
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) ay[q] = __builtin_elementwise_fma(w[q], dy[q], ay[q]);
+    if (D == 3) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) az[q] = __builtin_elementwise_fma(w[q], dz[q], az[q]);
+    }
+}
+
+// A target belongs to the close set if any of its coordinates is below kCloseCoord in magnitude
+// (see nbx_internal.h).  Evaluated on the same fp32 values by every kernel that needs it.
+template <int D>
+__device__ __forceinline__ bool in_close_set(float x, float y, float z) {
+    float m = __builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y));
+    if (D == 3) m = __builtin_fminf(m, __builtin_fabsf(z));
+    return m < kCloseCoord;
 }
 
 // Walks the virtual source-tile list of one launch: tile t of the list lives in real chunk
@@ -94,11 +162,36 @@ struct TileWalk {
     }
 };
 
+template <int D>
+__device__ __forceinline__ float4 load_source(const KArgs& a, const TileWalk& tw, unsigned tid) {
+    const int c = tw.chunk(a.chunk_first, a.chunk_skip);
+    const float* __restrict__ sp = a.pos_all + (size_t)c * D * a.pad + tw.k * kTile + tid;
+    float4 v;
+    v.x = sp[0];
+    v.y = sp[a.pad];
+    v.z = (D == 3) ? sp[2 * (size_t)a.pad] : 0.0f;
+    v.w = a.mass_all[(size_t)c * a.pad + tw.k * kTile + tid];
+    return v;
+}
+
+template <int D, typename T>
+__device__ __forceinline__ void store_result(const KArgs& a, float* __restrict__ out, unsigned i, T vx, T vy, T vz) {
+    if (a.accumulate) {
+        out[i] = (float)((double)out[i] + (double)vx);
+        out[(size_t)a.pad + i] = (float)((double)out[(size_t)a.pad + i] + (double)vy);
+        if (D == 3) out[2 * (size_t)a.pad + i] = (float)((double)out[2 * (size_t)a.pad + i] + (double)vz);
+    } else {
+        out[i] = (float)vx;
+        out[(size_t)a.pad + i] = (float)vy;
+        if (D == 3) out[2 * (size_t)a.pad + i] = (float)vz;
+    }
+}
 
 // -------------------------------------------------------------------------------------------------
-// LDS variant: 256 lanes, TPL targets per lane, sources staged in LDS as float4 {x,y,z,m}.
+// Exact LDS kernel: 256 lanes, TPL targets per lane, compare-and-select guard on every pair,
+// fp64 second-level accumulators.  Self-contained (no close-set pipeline).
 // -------------------------------------------------------------------------------------------------
-template <int D, int TPL, int WAVES, int GUARD, int UNROLL>
+template <int D, int TPL, int WAVES, int UNROLL>
 __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     __shared__ float4 tile[2][kTile];
     const unsigned tid = threadIdx.x;
@@ -119,29 +212,18 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     unsigned t = blockIdx.y * a.tiles_per_split;
     unsigned t_end = t + a.tiles_per_split;
     if (t_end > a.total_tiles) t_end = a.total_tiles;
-
     TileWalk w;
     w.seek(t, a.tiles_per_chunk);
-    auto load_src = [&](const TileWalk& tw) -> float4 {
-        const int c = tw.chunk(a.chunk_first, a.chunk_skip);
-        const float* __restrict__ sp = a.pos_all + (size_t)c * D * a.pad + tw.k * kTile + tid;
-        float4 v;
-        v.x = sp[0];
-        v.y = sp[a.pad];
-        v.z = (D == 3) ? sp[2 * (size_t)a.pad] : 0.0f;
-        v.w = a.mass_all[(size_t)c * a.pad + tw.k * kTile + tid];
-        return v;
-    };
 
     float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < t_end) nxt = load_src(w);
+    if (t < t_end) nxt = load_source<D>(a, w, tid);
     int buf = 0;
     for (; t < t_end; ++t) {
         tile[buf][tid] = nxt;
         __syncthreads();
         if (t + 1 < t_end) {  // next tile's global loads fly while this tile is consumed
             w.next(a.tiles_per_chunk);
-            nxt = load_src(w);
+            nxt = load_source<D>(a, w, tid);
         }
         float ax[TPL], ay[TPL], az[TPL];
 #pragma unroll
@@ -152,7 +234,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
             const float4 s = cur[j];  // same address in every lane: ds_read_b128 broadcast
 #pragma unroll
             for (int q = 0; q < TPL; ++q)
-                interact<D, GUARD>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
+                interact<D, GUARD_EXACT>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
         }
 #pragma unroll
         for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
@@ -161,33 +243,179 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
 
     float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
 #pragma unroll
-    for (int q = 0; q < TPL; ++q) {
-        const unsigned i = tgt0 + q * 256u;
-        if (a.accumulate) {
-            out[i] = (float)((double)out[i] + ox[q]);
-            out[(size_t)a.pad + i] = (float)((double)out[(size_t)a.pad + i] + oy[q]);
-            if (D == 3) out[2 * (size_t)a.pad + i] = (float)((double)out[2 * (size_t)a.pad + i] + oz[q]);
-        } else {
-            out[i] = (float)ox[q];
-            out[(size_t)a.pad + i] = (float)oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] = (float)oz[q];
+    for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fast packed LDS kernel: PAIRS float2 target pairs per lane (TPL = 2*PAIRS), no per-pair guard
+// (kTiny bias), fp32 second-level accumulators (the launcher keeps a slice at <= 256 tiles).
+// Targets of the close set are neither stored nor trusted: slice 0's workgroups append them to
+// close_list for accel_close_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int D, int PAIRS, int WAVES, int UNROLL, int STAGED = 0>
+__global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
+    constexpr int TPL = 2 * PAIRS;
+    __shared__ float4 tile[2][kTile];
+    const unsigned tid = threadIdx.x;
+    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+
+    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], ox[PAIRS], oy[PAIRS], oz[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const unsigned i0 = tgt0 + (2 * q) * 256u, i1 = i0 + 256u;
+        ix[q] = f2{tp[i0], tp[i1]};
+        iy[q] = f2{tp[(size_t)a.pad + i0], tp[(size_t)a.pad + i1]};
+        iz[q] = (D == 3) ? f2{tp[2 * (size_t)a.pad + i0], tp[2 * (size_t)a.pad + i1]} : f2{0.f, 0.f};
+        ox[q] = oy[q] = oz[q] = f2{0.f, 0.f};
+    }
+
+    unsigned t = blockIdx.y * a.tiles_per_split;
+    unsigned t_end = t + a.tiles_per_split;
+    if (t_end > a.total_tiles) t_end = a.total_tiles;
+    TileWalk w;
+    w.seek(t, a.tiles_per_chunk);
+
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < t_end) nxt = load_source<D>(a, w, tid);
+    int buf = 0;
+    for (; t < t_end; ++t) {
+        tile[buf][tid] = nxt;
+        __syncthreads();
+        if (t + 1 < t_end) {
+            w.next(a.tiles_per_chunk);
+            nxt = load_source<D>(a, w, tid);
+        }
+        f2 ax[PAIRS], ay[PAIRS], az[PAIRS];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
+        const float4* __restrict__ cur = tile[buf];
+#pragma unroll UNROLL
+        for (int j = 0; j < kTile; ++j) {
+            const float4 s = cur[j];
+            if (STAGED) {
+                interact2_staged<D, PAIRS>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q)
+                    interact2<D, GUARD_TINY>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
+        buf ^= 1;
+    }
+
+    float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned i = tgt0 + (2 * q + h) * 256u;
+            const float px = h ? ix[q].y : ix[q].x, py = h ? iy[q].y : iy[q].x, pz = h ? iz[q].y : iz[q].x;
+            if (in_close_set<D>(px, py, pz)) {
+                if (blockIdx.y == 0 && i < a.count) {
+                    const unsigned slot = atomicAdd(a.close_counter, 1u);
+                    a.close_list[slot] = i;
+                }
+            } else {
+                store_result<D>(a, out, i, h ? ox[q].y : ox[q].x, h ? oy[q].y : oy[q].x, h ? oz[q].y : oz[q].x);
+            }
         }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// SMEM variant: no LDS, no barriers.  Source arrays are read with wave-uniform addresses, which
-// hipcc turns into s_load_dwordx8 through the scalar cache; x/y/z/m of a source are then SGPR
-// operands of the VALU instructions (one SGPR per VOP2/VOP3 on gfx9-family encodings).
+// Close-set kernel: the targets listed by the fast kernel, exact guard, one target per lane, fp64
+// second level.  Grid (kCloseBlocksX, kCloseSlices): workgroup (bx, y) takes target blocks bx,
+// bx + gridDim.x, ... of the list against source slice y; an empty list costs one scalar load.
+// Writes close_acc[y][k][slot]; scatter_close_kernel folds the slices into acc.
 // -------------------------------------------------------------------------------------------------
-template <int D, int TPL, int WAVES, int GUARD, int BATCH>
+template <int D>
+__global__ __launch_bounds__(256) void accel_close_kernel(KArgs a) {
+    __shared__ float4 tile[2][kTile];
+    const unsigned tid = threadIdx.x;
+    const unsigned n = *a.close_counter;
+    const unsigned nblk = (n + 255u) / 256u;
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+    const unsigned tiles_per_slice = (a.total_tiles + gridDim.y - 1) / gridDim.y;
+
+    for (unsigned tb = blockIdx.x; tb < nblk; tb += gridDim.x) {
+        const unsigned slot = tb * 256u + tid;
+        const bool valid = slot < n;
+        const unsigned i = a.close_list[valid ? slot : 0];
+        const float ix = tp[i], iy = tp[(size_t)a.pad + i], iz = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+
+        unsigned t = blockIdx.y * tiles_per_slice;
+        unsigned t_end = t + tiles_per_slice;
+        if (t_end > a.total_tiles) t_end = a.total_tiles;
+        TileWalk w;
+        w.seek(t, a.tiles_per_chunk);
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < t_end) nxt = load_source<D>(a, w, tid);
+        int buf = 0;
+        for (; t < t_end; ++t) {
+            tile[buf][tid] = nxt;
+            __syncthreads();
+            if (t + 1 < t_end) {
+                w.next(a.tiles_per_chunk);
+                nxt = load_source<D>(a, w, tid);
+            }
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            const float4* __restrict__ cur = tile[buf];
+#pragma unroll 8
+            for (int j = 0; j < kTile; ++j) {
+                const float4 s = cur[j];
+                interact<D, GUARD_EXACT>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
+            }
+            ox += (double)ax; oy += (double)ay; oz += (double)az;
+            buf ^= 1;
+        }
+        if (valid) {
+            float* __restrict__ o = a.close_acc + (size_t)blockIdx.y * D * a.pad;
+            o[slot] = (float)ox;
+            o[(size_t)a.pad + slot] = (float)oy;
+            if (D == 3) o[2 * (size_t)a.pad + slot] = (float)oz;
+        }
+        __syncthreads();  // the next target block reuses the tile buffers
+    }
+}
+
+// Fold the close-set kernel's slices (fp64, slice order) into acc: slice 0 receives the sum (added to
+// what a preceding LOCAL pass left there when accumulating), the other slices are zeroed.
+template <int D>
+__global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
+    const unsigned n = *a.close_counter;
+    for (unsigned slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u) {
+        const unsigned i = a.close_list[slot];
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int y = 0; y < kCloseSlices; ++y) v += (double)a.close_acc[((size_t)y * D + k) * a.pad + slot];
+            float* __restrict__ dst = a.acc + (size_t)k * a.pad + i;
+            if (a.accumulate) {
+                *dst = (float)((double)*dst + v);
+            } else {
+                *dst = (float)v;
+                for (int s = 1; s < a.splits; ++s) a.acc[((size_t)s * D + k) * a.pad + i] = 0.0f;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// SMEM variant (exact): no LDS, no barriers.  Source arrays are read with wave-uniform addresses,
+// which hipcc turns into s_load_dwordx8 through the scalar cache; x/y/z/m of a source are then SGPR
+// operands of the VALU instructions.  Kept for A/B: an SGPR source operand slows v_fma_f32 on gfx950.
+// -------------------------------------------------------------------------------------------------
+template <int D, int TPL, int WAVES, int BATCH>
 __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
     const unsigned tid = threadIdx.x;
     const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     float ix[TPL], iy[TPL], iz[TPL];
-    double ox[TPL], oy[TPL], oz[TPL];  // second-level accumulators: one fp64 add per 256 pairs
+    double ox[TPL], oy[TPL], oz[TPL];
 #pragma unroll
     for (int q = 0; q < TPL; ++q) {
         const unsigned i = tgt0 + q * 256u;
@@ -227,7 +455,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
             for (int j = 0; j < BATCH; ++j)
 #pragma unroll
                 for (int q = 0; q < TPL; ++q)
-                    interact<D, GUARD>(sx[j], sy[j], sz[j], sm[j], ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
+                    interact<D, GUARD_EXACT>(sx[j], sy[j], sz[j], sm[j], ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
         }
 #pragma unroll
         for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
@@ -236,45 +464,37 @@ __global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
 
     float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
 #pragma unroll
-    for (int q = 0; q < TPL; ++q) {
-        const unsigned i = tgt0 + q * 256u;
-        if (a.accumulate) {
-            out[i] = (float)((double)out[i] + ox[q]);
-            out[(size_t)a.pad + i] = (float)((double)out[(size_t)a.pad + i] + oy[q]);
-            if (D == 3) out[2 * (size_t)a.pad + i] = (float)((double)out[2 * (size_t)a.pad + i] + oz[q]);
-        } else {
-            out[i] = (float)ox[q];
-            out[(size_t)a.pad + i] = (float)oy[q];
-            if (D == 3) out[2 * (size_t)a.pad + i] = (float)oz[q];
-        }
-    }
+    for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
 }
 
 // ---- variant table --------------------------------------------------------------------------------
-#define NBX_LDS(TPL, WAVES, GUARD, UNROLL) \
-    accel_lds_kernel<2, TPL, WAVES, GUARD, UNROLL>, accel_lds_kernel<3, TPL, WAVES, GUARD, UNROLL>
-#define NBX_SMEM(TPL, WAVES, GUARD, BATCH) \
-    accel_smem_kernel<2, TPL, WAVES, GUARD, BATCH>, accel_smem_kernel<3, TPL, WAVES, GUARD, BATCH>
+#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0
+#define NBX_SMEM(TPL, WAVES, BATCH) accel_smem_kernel<2, TPL, WAVES, BATCH>, accel_smem_kernel<3, TPL, WAVES, BATCH>, 0, 0
+#define NBX_FAST(PAIRS, WAVES, UNROLL) \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL>, 1, 256
+#define NBX_FASTS(PAIRS, WAVES, UNROLL) \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 1>, 1, 256
 #define NBX_NAME(n) n "_" NBX_STR(NBX_FLAVOUR)
 
 const KernelVariant kVariants[] = {
-    {NBX_NAME("lds_t1_w8_exact_u8"), 1, NBX_LDS(1, 8, GUARD_EXACT, 8)},
-    {NBX_NAME("lds_t2_w8_exact_u8"), 2, NBX_LDS(2, 8, GUARD_EXACT, 8)},
-    {NBX_NAME("lds_t2_w4_exact_u8"), 2, NBX_LDS(2, 4, GUARD_EXACT, 8)},
-    {NBX_NAME("lds_t4_w4_exact_u4"), 4, NBX_LDS(4, 4, GUARD_EXACT, 4)},
-    {NBX_NAME("lds_t4_w2_exact_u8"), 4, NBX_LDS(4, 2, GUARD_EXACT, 8)},
-    {NBX_NAME("smem_t1_w8_exact_b8"), 1, NBX_SMEM(1, 8, GUARD_EXACT, 8)},
-    {NBX_NAME("smem_t2_w8_exact_b8"), 2, NBX_SMEM(2, 8, GUARD_EXACT, 8)},
-    {NBX_NAME("smem_t2_w4_exact_b16"), 2, NBX_SMEM(2, 4, GUARD_EXACT, 16)},
-    {NBX_NAME("smem_t4_w4_exact_b8"), 4, NBX_SMEM(4, 4, GUARD_EXACT, 8)},
-    {NBX_NAME("lds_t2_w8_clamp_u8"), 2, NBX_LDS(2, 8, GUARD_CLAMP, 8)},    // experimental guard
-    {NBX_NAME("lds_t1_w8_tiny_u8"), 1, NBX_LDS(1, 8, GUARD_TINY, 8)},      // experimental guard
-    {NBX_NAME("lds_t2_w8_tiny_u8"), 2, NBX_LDS(2, 8, GUARD_TINY, 8)},      // experimental guard
-    {NBX_NAME("lds_t4_w4_tiny_u4"), 4, NBX_LDS(4, 4, GUARD_TINY, 4)},      // experimental guard
-    {NBX_NAME("lds_t4_w4_tiny_u8"), 4, NBX_LDS(4, 4, GUARD_TINY, 8)},      // experimental guard
-    {NBX_NAME("smem_t2_w8_tiny_b8"), 2, NBX_SMEM(2, 8, GUARD_TINY, 8)},    // experimental guard
-    {NBX_NAME("smem_t4_w4_tiny_b8"), 4, NBX_SMEM(4, 4, GUARD_TINY, 8)},    // experimental guard
-    {NBX_NAME("smem_t2_w8_clamp_b8"), 2, NBX_SMEM(2, 8, GUARD_CLAMP, 8)},  // experimental guard
+    {NBX_NAME("lds_t1_w8_exact_u8"), 1, NBX_LDS(1, 8, 8)},
+    {NBX_NAME("lds_t2_w8_exact_u8"), 2, NBX_LDS(2, 8, 8)},
+    {NBX_NAME("lds_t4_w4_exact_u4"), 4, NBX_LDS(4, 4, 4)},
+    {NBX_NAME("smem_t1_w8_exact_b8"), 1, NBX_SMEM(1, 8, 8)},
+    {NBX_NAME("smem_t2_w4_exact_b16"), 2, NBX_SMEM(2, 4, 16)},
+    {NBX_NAME("fastpk_t2_w8_u8"), 2, NBX_FAST(1, 8, 8)},
+    {NBX_NAME("fastpk_t4_w4_u4"), 4, NBX_FAST(2, 4, 4)},
+    {NBX_NAME("fastpk_t4_w8_u4"), 4, NBX_FAST(2, 8, 4)},
+    {NBX_NAME("fastpk_t8_w4_u4"), 8, NBX_FAST(4, 4, 4)},
+    {NBX_NAME("fastpk_t8_w4_u2"), 8, NBX_FAST(4, 4, 2)},
+    {NBX_NAME("fastpk_t8_w4_u8"), 8, NBX_FAST(4, 4, 8)},
+    {NBX_NAME("fastpk_t8_w3_u4"), 8, NBX_FAST(4, 3, 4)},
+    {NBX_NAME("fastpks_t8_w4_u2"), 8, NBX_FASTS(4, 4, 2)},
+    {NBX_NAME("fastpks_t8_w4_u4"), 8, NBX_FASTS(4, 4, 4)},
+    {NBX_NAME("fastpks_t8_w3_u2"), 8, NBX_FASTS(4, 3, 2)},
+    {NBX_NAME("fastpks_t4_w8_u4"), 4, NBX_FASTS(2, 8, 4)},
+    {NBX_NAME("fastpks_t4_w4_u4"), 4, NBX_FASTS(2, 4, 4)},
+    {NBX_NAME("fastpks_t16_w2_u2"), 16, NBX_FASTS(8, 2, 2)},
 };
 
 }  // namespace
@@ -284,5 +504,15 @@ const KernelVariant* NBX_CAT(variants_, NBX_FLAVOUR)(int* count) {
     *count = (int)(sizeof(NBX_FLAVOUR::kVariants) / sizeof(NBX_FLAVOUR::kVariants[0]));
     return NBX_FLAVOUR::kVariants;
 }
+
+#ifdef NBX_EMIT_CLOSE_KERNELS
+// one copy of the close-set kernels (emitted by the scalar flavour's translation unit)
+void close_kernels(void (**k2)(KArgs), void (**k3)(KArgs), void (**s2)(KArgs), void (**s3)(KArgs)) {
+    *k2 = NBX_FLAVOUR::accel_close_kernel<2>;
+    *k3 = NBX_FLAVOUR::accel_close_kernel<3>;
+    *s2 = NBX_FLAVOUR::scatter_close_kernel<2>;
+    *s3 = NBX_FLAVOUR::scatter_close_kernel<3>;
+}
+#endif
 
 }  // namespace nbx

@@ -1,5 +1,7 @@
-// force_launch.hip -- host-side launcher of the force kernel: merges the variant tables of the two
-// code-generation flavours of force_kernel.hip, checks launch shapes on the host, sizes the grid.
+// force_launch.hip -- host-side launcher of one force evaluation: merges the variant tables of the two
+// code-generation flavours of force_kernel.hip, checks launch shapes on the host, sizes the grids,
+// and for fast variants runs the close-set pipeline (counter reset -> fast kernel -> close-set kernel
+// -> scatter), all asynchronous on the caller's stream with no host read-back.
 #include "nbx_internal.h"
 
 #include <cstring>
@@ -10,39 +12,57 @@ namespace {
 
 struct Table {
     std::vector<KernelVariant> v;
-    int def = 0;
+    int def = 0, def_exact = 0;
+    void (*close2)(KArgs) = nullptr;
+    void (*close3)(KArgs) = nullptr;
+    void (*scat2)(KArgs) = nullptr;
+    void (*scat3)(KArgs) = nullptr;
     Table() {
         int n = 0;
         const KernelVariant* a = variants_scalar(&n);
         for (int i = 0; i < n; ++i) v.push_back(a[i]);
         const KernelVariant* b = variants_slp(&n);
         for (int i = 0; i < n; ++i) v.push_back(b[i]);
-        for (size_t i = 0; i < v.size(); ++i)
+        for (size_t i = 0; i < v.size(); ++i) {
             if (std::strcmp(v[i].name, NBX_DEFAULT_VARIANT) == 0) def = (int)i;
+            if (std::strcmp(v[i].name, NBX_DEFAULT_EXACT_VARIANT) == 0) def_exact = (int)i;
+        }
+        close_kernels(&close2, &close3, &scat2, &scat3);
     }
 };
 const Table& table() {
     static const Table t;
     return t;
 }
+bool valid(int v) { return v >= 0 && v < (int)table().v.size(); }
 
 }  // namespace
 
 int num_variants() { return (int)table().v.size(); }
-const char* variant_name(int v) { return (v >= 0 && v < num_variants()) ? table().v[v].name : "?"; }
-int variant_tpl(int v) { return (v >= 0 && v < num_variants()) ? table().v[v].tpl : 1; }
+const char* variant_name(int v) { return valid(v) ? table().v[v].name : "?"; }
+int variant_tpl(int v) { return valid(v) ? table().v[v].tpl : 1; }
+int variant_is_fast(int v) { return valid(v) ? table().v[v].fast : 0; }
+int variant_max_tiles_per_slice(int v) { return valid(v) ? table().v[v].max_tiles_per_slice : 0; }
+int variant_by_name(const char* name) {
+    for (int i = 0; i < num_variants(); ++i)
+        if (std::strcmp(table().v[i].name, name) == 0) return i;
+    return -1;
+}
 int default_variant() { return table().def; }
+int default_exact_variant() { return table().def_exact; }
 
 hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
-    if ((dim != 2 && dim != 3) || L.pad == 0 || L.pad % kPadQuantum != 0 || L.splits < 1 || L.vchunks < 1)
+    if ((dim != 2 && dim != 3) || L.pad == 0 || L.pad % kPadQuantum != 0 || L.splits < 1 || L.vchunks < 1 ||
+        L.count > L.pad)
         return hipErrorInvalidValue;
-    const int v = (L.variant >= 0 && L.variant < num_variants()) ? L.variant : default_variant();
+    const int v = valid(L.variant) ? L.variant : default_variant();
     const KernelVariant& V = table().v[v];
     KArgs a;
     a.pos_all = L.pos_all;
     a.mass_all = L.mass_all;
     a.acc = L.acc;
     a.pad = L.pad;
+    a.count = L.count;
     a.tiles_per_chunk = L.pad / kTile;
     a.total_tiles = (unsigned)L.vchunks * a.tiles_per_chunk;
     a.tiles_per_split = (a.total_tiles + (unsigned)L.splits - 1) / (unsigned)L.splits;
@@ -50,12 +70,32 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.chunk_first = L.chunk_first;
     a.chunk_skip = L.chunk_skip;
     a.accumulate = L.accumulate;
-    // host-side shape check: every target block and every source tile lies inside its chunk
+    a.splits = L.splits;
+    a.close_list = L.close_list;
+    a.close_counter = L.close_counter;
+    a.close_acc = L.close_acc;
+    // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
+    if (V.fast && (!L.close_list || !L.close_counter || !L.close_acc)) return hipErrorInvalidValue;
+    if (V.max_tiles_per_slice > 0 && a.tiles_per_split > (unsigned)V.max_tiles_per_slice) return hipErrorInvalidValue;
+
+    if (V.fast) {
+        hipError_t e = hipMemsetAsync(L.close_counter, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+    }
     dim3 grid(L.pad / tgt_per_block, (unsigned)L.splits, 1), block(256, 1, 1);
-    void (*k)(KArgs) = (dim == 3) ? V.k3 : V.k2;
-    hipLaunchKernelGGL(k, grid, block, 0, stream, a);
+    hipError_t e = hipSuccess;
+    if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL((dim == 3) ? V.k3 : V.k2, grid, block, 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;
+    if (!V.fast) return hipSuccess;
+    hipLaunchKernelGGL((dim == 3) ? table().close3 : table().close2, dim3(kCloseBlocksX, kCloseSlices, 1), block, 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((dim == 3) ? table().scat3 : table().scat2, dim3(64, 1, 1), block, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@ int fail(int code, const char* msg) {
     } while (0)
 
 constexpr int kEventPairs = 512;
+constexpr int kMaxSplits = 256;
 
 }  // namespace
 
@@ -56,6 +57,12 @@ struct nbx_ctx {
     double *x64 = nullptr, *v64 = nullptr, *m64 = nullptr;
     float* acc = nullptr;
     int acc_splits_alloc = 0;
+    // fast-path workspace (close-set pipeline) and its preconditions
+    unsigned* close_list = nullptr;
+    unsigned* close_counter = nullptr;
+    float* close_acc = nullptr;
+    bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
+    int variant_req = -1;       // what the caller asked for (-1: library default)
     // boundary staging
     double* stage = nullptr;
     size_t stage_bytes = 0;
@@ -76,26 +83,51 @@ int ensure_stage(nbx_ctx* c, size_t bytes) {
     return NBX_OK;
 }
 
-// Source slices: enough workgroups to give every SIMD >= 2 waves even for a small shard.
-int auto_splits(const nbx_ctx* c, int tpl) {
-    const unsigned tgt_blocks = c->pad / (256u * (unsigned)tpl);
+// The variant actually launched: the caller's choice (or the default), demoted to the exact default when
+// the fast path's preconditions do not hold for this context.
+int effective_variant(const nbx_ctx* c) {
+    int v = c->variant_req >= 0 ? c->variant_req : default_variant();
+    if (variant_is_fast(v) && c->force_exact) v = default_exact_variant();
+    return v;
+}
+
+// Source slices: enough workgroups to give every SIMD several waves even for a small shard, and no
+// more tiles per slice than the kernel's fp32 second-level sums want.
+int auto_splits(const nbx_ctx* c, int variant) {
+    const unsigned tgt_blocks = c->pad / (256u * (unsigned)variant_tpl(variant));
     const unsigned want_blocks = (unsigned)c->num_cus * 4u;  // 4 workgroups (16 waves) per CU
     unsigned s = (want_blocks + tgt_blocks - 1) / tgt_blocks;
     const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
     const unsigned max_s = tiles / 8 ? tiles / 8 : 1;  // keep >= 8 tiles (2048 sources) per slice
     if (s > max_s) s = max_s;
+    const int cap = variant_max_tiles_per_slice(variant);
+    if (cap > 0) {
+        const unsigned need = (tiles + (unsigned)cap - 1) / (unsigned)cap;
+        if (s < need) s = need;
+    }
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > (unsigned)kMaxSplits) s = (unsigned)kMaxSplits;
     return (int)s;
 }
 
-
 int ensure_acc(nbx_ctx* c) {
-    if (!c->splits_user) c->splits = auto_splits(c, variant_tpl(c->variant));
-    if (c->acc && c->acc_splits_alloc >= c->splits) return NBX_OK;
-    if (c->acc) { HIP_TRY(hipFree(c->acc)); c->acc = nullptr; }
-    HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
-    c->acc_splits_alloc = c->splits;
+    c->variant = effective_variant(c);
+    if (!c->splits_user) c->splits = auto_splits(c, c->variant);
+    if (const int cap = variant_max_tiles_per_slice(c->variant)) {  // a caller's slice count is a lower bound
+        const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
+        const int need = (int)((tiles + (unsigned)cap - 1) / (unsigned)cap);
+        if (c->splits < need) c->splits = need;
+    }
+    if (!(c->acc && c->acc_splits_alloc >= c->splits)) {
+        if (c->acc) { HIP_TRY(hipFree(c->acc)); c->acc = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
+        c->acc_splits_alloc = c->splits;
+    }
+    if (variant_is_fast(c->variant) && !c->close_acc) {
+        HIP_TRY(hipMalloc((void**)&c->close_list, (size_t)c->pad * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&c->close_counter, sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&c->close_acc, (size_t)kCloseSlices * c->dim * c->pad * sizeof(float)));
+    }
     return NBX_OK;
 }
 
@@ -158,6 +190,7 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     if (pad == 0) pad = kPadQuantum;
     c->pad = (unsigned)pad;
     c->variant = default_variant();
+    c->variant_req = -1;
 #define CTX_TRY(expr)                                                            \
     do {                                                                         \
         hipError_t e_ = (expr);                                                  \
@@ -189,6 +222,9 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->v64) (void)hipFree(c->v64);
     if (c->m64) (void)hipFree(c->m64);
     if (c->acc) (void)hipFree(c->acc);
+    if (c->close_list) (void)hipFree(c->close_list);
+    if (c->close_counter) (void)hipFree(c->close_counter);
+    if (c->close_acc) (void)hipFree(c->close_acc);
     if (c->stage) (void)hipFree(c->stage);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
@@ -237,6 +273,25 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
         HIP_TRY(hipMalloc((void**)&c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)));
         c->own_gather = true;
     }
+    // Preconditions of the fast (unguarded) force path, checked on the caller's array while it is
+    // borrowed: every mass small enough for the kTiny bias, and the close set a small part of the shard.
+    {
+        const char* base = static_cast<const char*>(bodies);
+        const size_t lo = (size_t)c->shard * c->shard_len;
+        double mmax = 0.0;
+        size_t close = 0;
+        for (size_t i = 0; i < c->n_total; ++i) {
+            const double* b = reinterpret_cast<const double*>(base + i * stride_bytes);
+            const double m = b[2 * c->dim] < 0 ? -b[2 * c->dim] : b[2 * c->dim];
+            if (!(m <= mmax)) mmax = m;  // also catches NaN
+            if (i >= lo && i < lo + c->count) {
+                double cm = b[0] < 0 ? -b[0] : b[0];
+                for (int k = 1; k < c->dim; ++k) { const double v = b[k] < 0 ? -b[k] : b[k]; if (v < cm) cm = v; }
+                if (cm < (double)kCloseCoord) ++close;
+            }
+        }
+        c->force_exact = !(mmax <= kFastMaxMass) || close * 8 > c->count;
+    }
     const size_t bytes = c->n_total * stride_bytes;
     rc = ensure_stage(c, bytes ? bytes : 8);
     if (rc) return rc;
@@ -254,12 +309,28 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
 
 int nbx_ctx_set_tuning(nbx_ctx* c, int source_splits, int variant) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
-    if (source_splits < 0 || source_splits > 64) return fail(NBX_ERR_INVALID, "source_splits must be in [0,64]");
+    if (source_splits < 0 || source_splits > kMaxSplits) return fail(NBX_ERR_INVALID, "source_splits must be in [0,256]");
     if (variant < -1 || variant >= num_variants()) return fail(NBX_ERR_INVALID, "unknown kernel variant");
     c->splits_user = source_splits > 0;
     if (c->splits_user) c->splits = source_splits;
-    c->variant = variant < 0 ? default_variant() : variant;
+    c->variant_req = variant;
     c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_effective_tuning(nbx_ctx* c, int* variant, int* source_splits) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    const int v = effective_variant(c);
+    if (variant) *variant = v;
+    if (source_splits) {
+        int s = c->splits_user ? c->splits : auto_splits(c, v);
+        if (const int cap = variant_max_tiles_per_slice(v)) {
+            const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
+            const int need = (int)((tiles + (unsigned)cap - 1) / (unsigned)cap);
+            if (s < need) s = need;
+        }
+        *source_splits = s;
+    }
     return NBX_OK;
 }
 
@@ -272,17 +343,18 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     if (rc) return rc;
     if (which != NBX_SRC_REMOTE) { rc = ensure_acc(c); if (rc) return rc; }
     AccelLaunch L;
-    L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad;
+    L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
+    L.close_list = c->close_list; L.close_counter = c->close_counter; L.close_acc = c->close_acc;
     L.chunk_skip = INT_MAX; L.accumulate = 0;
     if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
     else { L.chunk_first = 0; L.vchunks = c->n_shards - 1; L.chunk_skip = c->shard; L.accumulate = 1; }
     if (L.vchunks == 0) return NBX_OK;  // REMOTE with a single shard: nothing to add
     const bool timed = c->ev_used < kEventPairs;
-    if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], c->stream));
+    if (timed) { L.ev_start = c->ev0[c->ev_used]; L.ev_stop = c->ev1[c->ev_used]; }
     HIP_TRY(launch_accel(c->dim, L, c->stream));
-    if (timed) { HIP_TRY(hipEventRecord(c->ev1[c->ev_used], c->stream)); ++c->ev_used; }
+    if (timed) ++c->ev_used;
     ++c->launches_since_query;
     c->have_accel = true;
     return NBX_OK;

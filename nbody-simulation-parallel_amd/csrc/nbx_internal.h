@@ -11,27 +11,51 @@ namespace nbx {
 // Source tile = bodies staged per LDS fill (BASELINE config 2: "LDS tile=256") = workgroup size.
 constexpr int kTile = 256;
 // Shard arrays are padded to a multiple of this many bodies so that every force-kernel variant
-// (up to 4 targets per lane x 256 lanes) sees whole target blocks and whole source tiles.
-constexpr int kPadQuantum = 1024;
+// (up to 16 targets per lane x 256 lanes) sees whole target blocks and whole source tiles.
+constexpr int kPadQuantum = 4096;
 
 // Smallest fp32 that is >= the reference's fp64 skip threshold 1e-10 (methods.cpp:24): for any fp32
 // r2, (r2 < kR2SkipF) == ((double)r2 < 1e-10).   0x2edbe6ff = 1.00000001335e-10f.
 constexpr float kR2SkipF = 1.0e-10f;
 static_assert((double)kR2SkipF >= 1e-10, "fp32 threshold must not round below the fp64 one");
 
-// How one force launch walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
+// ---- close-pair bookkeeping of the fast force path (force_kernel.hip) --------------------------------
+// The fast kernel carries no per-pair guard: it biases r^2 by kTiny so that coincident bodies (d = 0)
+// contribute exactly 0 and 1/r^2 stays finite.  That is exact unless a pair has 0 < r^2 < ~1e-6.  Two
+// DISTINCT fp32 coordinates a, b differ by at least the fp32 spacing at min(|a|,|b|); if every
+// coordinate of a target is >= kCloseCoord = 8192 in magnitude, any source that differs from it in
+// some coordinate is at least ulp(4096..8192) = 4.88e-4 away in that coordinate, i.e. r^2 >= 2.38e-7,
+// where the bias kTiny = 2^-47 moves r^2 by at most half a unit roundoff (2^-25).  Targets with a
+// coordinate below kCloseCoord ("close set", ~0.25 % of the reference's uniform bodies) are left
+// unwritten by the fast kernel, listed, and evaluated by accel_close_kernel with the exact
+// compare-and-select guard.  The result therefore has the reference's skip semantics for every pair.
+constexpr float kTiny = 0x1p-47f;          // 7.1e-15
+constexpr float kCloseCoord = 8192.0f;
+// m / (kTiny^2) must stay finite in fp32 for a coincident source: masses above this force the exact path.
+constexpr double kFastMaxMass = 1.0e10;
+constexpr int kCloseSlices = 32;           // source slices of the close-set kernel
+constexpr int kCloseBlocksX = 64;          // target-block lanes of the close-set kernel's grid
+
+// How one force evaluation walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
 struct AccelLaunch {
     const float* pos_all;
     const float* mass_all;
     float* acc;          // [splits][dim][pad] partial accelerations of the target shard
     unsigned pad;        // bodies per chunk (multiple of kPadQuantum)
+    unsigned count;      // real targets in the shard (<= pad)
     int tgt_chunk;       // chunk whose bodies are the targets
     int chunk_first;     // first real chunk of the virtual source list
     int vchunks;         // number of chunks in the virtual source list
     int chunk_skip;      // real chunk left out of the list (INT_MAX: none)
     int splits;          // gridDim.y: slices of the virtual tile list
     int accumulate;      // 0: acc = result, 1: acc += result
-    int variant;         // force-kernel variant id (see force_kernel.hip)
+    int variant;         // force-kernel variant id
+    // workspace of the fast path (may be null for exact variants)
+    unsigned* close_list;     // [pad] target indices of the close set
+    unsigned* close_counter;  // [1]
+    float* close_acc;         // [kCloseSlices][dim][pad]
+    // optional: recorded on the stream immediately before / after the main force kernel
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 // Kernel-side view of one force launch (built by launch_accel from an AccelLaunch).
@@ -40,11 +64,16 @@ struct KArgs {
     const float* __restrict__ mass_all;
     float* __restrict__ acc;
     unsigned pad;
+    unsigned count;
     unsigned tiles_per_chunk;
     unsigned total_tiles;      // vchunks * tiles_per_chunk
     unsigned tiles_per_split;
     int tgt_chunk, chunk_first, chunk_skip;
     int accumulate;
+    int splits;
+    unsigned* __restrict__ close_list;
+    unsigned* __restrict__ close_counter;
+    float* __restrict__ close_acc;
 };
 
 struct KernelVariant {
@@ -52,17 +81,24 @@ struct KernelVariant {
     int tpl;              // targets per lane
     void (*k2)(KArgs);    // D = 2
     void (*k3)(KArgs);    // D = 3
+    int fast;             // 1: unguarded fast kernel + close-set pipeline (exact overall)
+    int max_tiles_per_slice;  // > 0: the kernel's fp32 second-level sums want at most this many tiles per slice
 };
 // force_kernel.hip, compiled once per code-generation flavour
 const KernelVariant* variants_slp(int* count);
 const KernelVariant* variants_scalar(int* count);
+void close_kernels(void (**k2)(KArgs), void (**k3)(KArgs), void (**s2)(KArgs), void (**s3)(KArgs));
 
 // force_launch.hip
 hipError_t launch_accel(int dim, const AccelLaunch& a, hipStream_t stream);
 int num_variants();
 const char* variant_name(int variant);
 int variant_tpl(int variant);
-int default_variant();
+int variant_is_fast(int variant);
+int variant_max_tiles_per_slice(int variant);
+int variant_by_name(const char* name);
+int default_variant();        // the fast default
+int default_exact_variant();  // used when the fast path's preconditions do not hold
 
 // state_kernels.hip
 struct PackArgs {

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
-PAD_QUANTUM = 1024  # csrc/nbx_internal.h kPadQuantum
+PAD_QUANTUM = 4096  # csrc/nbx_internal.h kPadQuantum
 
 
 @dataclass(frozen=True)

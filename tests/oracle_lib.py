@@ -176,12 +176,15 @@ def have_reference() -> bool:
 # (T2) is BASELINE.json's "accelerations within 1e-5 relative"; bodies whose pair forces cancel to
 # less than 1/16 of their magnitude sum (about 2 % of uniform-random bodies; kappa reaches ~250 at
 # N=4096) cannot meet a plain relative bound in fp32 by construction -- they are held to (T1).
-# (T1)'s constant is the worst case of ONE fp32 pair term m*d/(r^2)^2: with unit roundoff
-# u = 2^-24 = 6e-8, d carries 1u, r^2 5u (entering squared: 10u), v_rcp_f32 1 ulp = 2u (squared:
-# 4u), three more products 3u  => 18u = 1.1e-6, plus the 256-term fp32 inner sums; measured maxima
-# are 1.0-1.7e-6 when one close neighbour dominates the sum.  2.5e-6 = 42u.
+# (T1)'s constant: with unit roundoff u = 2^-24 = 6e-8, ONE fp32 pair term m*d/(r^2)^2 carries at most
+# 18u (d: 1u; r^2: 5u, entering squared: 10u; v_rcp_f32 1 ulp = 2u, squared: 4u; three products: 3u),
+# and the term then rides through ~512 fp32 additions (256-term tile sum + up to 256 tile flushes;
+# a term added early into a sum it dominates sees every later rounding): rms sqrt(512)*u/sqrt(3) = 13u,
+# 3.5 sigma = 46u.  18u + 46u = 64u = 3.8e-6.  Measured maxima: 1.0-1.7e-6 on uniform bodies, 2.5-2.6e-6
+# when one close or very massive neighbour dominates a sum (reproduced by a numpy fp32 emulation with
+# a correctly rounded reciprocal, so it is the arithmetic, not the kernel).
 TOL_REL = 1.0e-5
-TOL_BACKWARD = 2.5e-6
+TOL_BACKWARD = 4.0e-6
 KAPPA_WELL = 16.0
 
 

@@ -90,7 +90,7 @@ def test_shard_layout_logic():
     assert L.shard_len == 131072 and L.shard_pad == 131072 and L.bounds() == (393216, 524288) and L.count == 131072
     assert L.pos_all_shape() == (8, 3, 131072) and L.interactions_per_step() == 131072 * (1 << 20)
     R = SL(n_total=10, n_shards=4, shard=3, dim=2)       # ragged: shards of 3,3,3,1
-    assert R.shard_len == 3 and R.shard_pad == 1024 and R.bounds() == (9, 10) and R.count == 1
+    assert R.shard_len == 3 and R.shard_pad == 4096 and R.bounds() == (9, 10) and R.count == 1
     E = SL(n_total=2, n_shards=4, shard=3, dim=2)        # more ranks than bodies
     assert E.count == 0 and E.bounds() == (2, 2)
     assert sum(SL(1001, 7, g, 3).count for g in range(7)) == 1001

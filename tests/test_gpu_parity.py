@@ -48,9 +48,8 @@ def test_every_variant(nbx, oracle):
         with nbx.Context(n, dim) as c:
             c.upload(b)
             for v, name in enumerate(names):
-                if "clamp" in name or "tiny" in name:
-                    continue  # experimental guard: exact only without 0 < r^2 < 1e-10 pairs; covered below
                 c.set_tuning(0, v)
+                assert c.effective_tuning()[0] == name
                 c.compute_accel()
                 assert_force_parity(c.forces(oracle.G), ref, S, f"variant {name} D={dim}")
 
@@ -196,3 +195,89 @@ def test_wrong_order_is_an_error(nbx, oracle):
         c.upload(oracle.generate(1, 16, 3))
         with pytest.raises(nbx.NbxError):
             c.step(1.0, 1)
+
+
+def _fast_variants(nbx):
+    return [(i, n) for i, n in enumerate(nbx.variants()) if n.startswith("fast")]
+
+
+def test_fast_path_close_set_semantics(nbx, oracle):
+    """The unguarded fast kernels + close-set pipeline must reproduce the reference's skip rule for
+    every pair: sub-threshold pairs (0 < r^2 < 1e-10), exact duplicates and ordinary close pairs, both
+    for targets inside the close set (a coordinate below 8192) and outside it."""
+    n, dim = 20000, 3
+    b = oracle.generate(91, n, dim)
+    b[:1500, 0] = 1.0 + 8000.0 * (b[:1500, 0] / 1e7)          # 7.5 % of the bodies near the x = 0 plane
+    b[200, :3] = (3.0, 5.0e6, 5.0e6)
+    b[201, :3] = (3.0 + 4.8e-7, 5.0e6, 5.0e6)                 # 2 ulp apart: r^2 = 2.3e-13 -> skipped
+    b[300, :3] = (100.0, 2.0e6, 2.0e6)
+    b[301, :3] = (100.0 + 7.7e-6, 2.0e6, 2.0e6)               # r^2 = 5.9e-11 -> skipped
+    b[302, :3] = (100.0 + 1.6e-5, 2.0e6, 2.0e6)               # r^2 = 2.6e-10 from body 300 -> counted
+    b[5000:5004, :3] = b[4999, :3]                            # exact duplicates far from every plane
+    b[6000, :3] = (9000.0, 9000.0, 9000.0)
+    b[6001, :3] = (9000.0 + 9.765625e-4, 9000.0, 9000.0)      # closest possible pair outside the close set
+    b = oracle.round_inputs_to_f32(b)
+    ref = oracle.brute_force_seq(b)
+    S = oracle.force_magnitude_sums(b)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        for v, name in _fast_variants(nbx):
+            c.set_tuning(0, v)
+            assert c.effective_tuning()[0] == name, "preconditions hold: the fast variant itself must run"
+            c.compute_accel()
+            f = c.forces(oracle.G)
+            assert_force_parity(f, ref, S, f"fast variant {name}")
+            # the skipped pair exerts nothing: bodies 200/201 feel the same field up to their 5e-7 offset
+            c.compute_accel()
+            assert np.array_equal(f, c.forces(oracle.G)), "bit-reproducible despite the atomically built list"
+    # sharded: close-set targets go through LOCAL (store) and REMOTE (accumulate) scatter paths
+    v0 = _fast_variants(nbx)[0][0]
+    for r in range(3):
+        with nbx.Context(n, dim, n_shards=3, shard=r) as c:
+            c.upload(b)
+            c.set_tuning(0, v0)
+            c.compute_accel(nbx.SRC_LOCAL)
+            c.compute_accel(nbx.SRC_REMOTE)
+            lo = r * c.shard_len
+            assert_force_parity(c.forces(oracle.G), ref[lo:lo + c.count], S[lo:lo + c.count], f"fast sharded r={r}")
+
+
+def test_fast_path_preconditions_fall_back_to_guarded_kernel(nbx, oracle):
+    n, dim = 3000, 3
+    fast = _fast_variants(nbx)[0]
+    # (1) a mass above 1e10 would overflow m/kTiny^2 for a coincident source
+    b = oracle.round_inputs_to_f32(oracle.generate(5, n, dim))
+    b[7, -1] = float(np.float32(3.0e12))
+    b[8, :3] = b[7, :3]
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_tuning(0, fast[0])
+        assert "exact" in c.effective_tuning()[0]
+        c.compute_accel()
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "huge mass")
+    # (2) a whole system inside the close region (small box): guarded kernel for everything
+    b = oracle.generate(6, n, dim)
+    b[:, :3] = b[:, :3] / 1e4
+    b = oracle.round_inputs_to_f32(b)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        assert "exact" in c.effective_tuning()[0]
+        c.compute_accel()
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "small box")
+    # (3) bodies that DRIFT into the close region after upload stay correct (the list is rebuilt every evaluation)
+    b = oracle.round_inputs_to_f32(oracle.generate(7, n, dim))
+    b[:, 3:6] = 0.0
+    b[:400, 0] = 9000.0 + np.arange(400) * 3.0
+    b[:400, 3] = -100.0                                        # 10 steps of dt=1 carry them across x = 8192
+    b = oracle.round_inputs_to_f32(b)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_tuning(0, fast[0])
+        assert c.effective_tuning()[0] == fast[1]
+        c.step(1.0, 10, oracle.G)
+        cur = b.copy()
+        c.download(cur)
+        assert (cur[:400, 0] < 8192).sum() >= 60
+        c.compute_accel()
+        cr = oracle.round_inputs_to_f32(cur)
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(cr), oracle.force_magnitude_sums(cr), "after drift")

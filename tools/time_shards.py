@@ -1,0 +1,28 @@
+"""Per-rank cost of the sharded step on ONE GPU: a context with n_shards=G, shard=r runs its LOCAL and
+REMOTE force passes + kick/drift exactly as one rank of a G-GPU run would (without the all-gather)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import nbody_amd as nbx
+from oracle_lib import Oracle
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+b = Oracle().generate(1, n, 3)
+base = None
+for G in (1, 2, 4, 8):
+    with nbx.Context(n, 3, n_shards=G, shard=G // 2) as c:
+        c.upload(b)
+        def step():
+            if G == 1:
+                c.compute_accel(nbx.SRC_ALL)
+            else:
+                c.compute_accel(nbx.SRC_LOCAL); c.compute_accel(nbx.SRC_REMOTE)
+            c.kick_drift(1.0)
+        step(); c.synchronize(); c.kernel_time()
+        t0 = time.perf_counter()
+        K = 5
+        for _ in range(K): step()
+        c.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        ms, cnt = c.kernel_time()
+        base = base or dt
+        print(f"G={G}: wall {dt*1e3:8.3f} ms/step (ideal {base/G*1e3:8.3f}, efficiency {base/G/dt*100:5.1f}%)  main-kernel sum {ms*cnt/K:8.3f} ms/step  tuning {c.effective_tuning()}", flush=True)
