@@ -101,9 +101,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # synthetic bodies, identical on every rank (reference generator ranges; seeded)
-    from oracle_lib import Oracle  # generator only: inputs, not the measured path
-    bodies = Oracle().generate(args.seed, args.bodies, args.dim)
+    # synthetic bodies, identical on every rank (the reference generator's stream, seeded)
+    bodies = nbx.uniform_bodies(args.bodies, args.dim, args.seed)
     N = args.bodies
 
     system = nbx.package.dist.make_hip_system(bodies, args.dim, rank=rank, world_size=world, device_index=local_rank,

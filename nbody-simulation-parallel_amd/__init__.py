@@ -12,7 +12,8 @@ from .capi import (  # noqa: F401
     ABI, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE, Context, NbxError,
     body_stride, brute_force_hip_n_body, device_count, leapfrog_hip_n_body, load_library, variants,
 )
-from . import sharding  # noqa: E402,F401
+from . import generate, sharding  # noqa: E402,F401
+from .generate import plummer_bodies, uniform_bodies  # noqa: E402,F401
 
 
 def __getattr__(name):

@@ -246,18 +246,25 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
 }
 
+template <int D>
+__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile]);
+
 // -------------------------------------------------------------------------------------------------
 // Fast packed LDS kernel: PAIRS float2 target pairs per lane (TPL = 2*PAIRS), no per-pair guard
 // (kTiny bias), fp32 second-level accumulators (the launcher keeps a slice at <= 256 tiles).
-// Targets of the close set are neither stored nor trusted: slice 0's workgroups append them to
-// close_list for accel_close_kernel.
+// Flagged (bad) targets are neither stored nor trusted; the launch's extra workgroups
+// (blockIdx.x < close_blocks) evaluate them with the guard (close_set_path below).
 // -------------------------------------------------------------------------------------------------
 template <int D, int PAIRS, int WAVES, int UNROLL, int STAGED = 0>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
+    if (blockIdx.x < a.close_blocks) {  // the launch's extra workgroups: guarded evaluation of the close set
+        close_set_path<D>(a, tile);
+        return;
+    }
     const unsigned tid = threadIdx.x;
-    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
+    const unsigned tgt0 = (blockIdx.x - a.close_blocks) * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], ox[PAIRS], oy[PAIRS], oz[PAIRS];
@@ -312,43 +319,95 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned i = tgt0 + (2 * q + h) * 256u;
-            const float px = h ? ix[q].y : ix[q].x, py = h ? iy[q].y : iy[q].x, pz = h ? iz[q].y : iz[q].x;
-            if (in_close_set<D>(px, py, pz)) {
-                if (blockIdx.y == 0 && i < a.count) {
-                    const unsigned slot = atomicAdd(a.close_counter, 1u);
-                    a.close_list[slot] = i;
-                }
-            } else {
+            if (!a.bad_flag[i])  // flagged targets belong to close_set_path + scatter_close_kernel
                 store_result<D>(a, out, i, h ? ox[q].y : ox[q].x, h ? oy[q].y : oy[q].x, h ? oz[q].y : oz[q].x);
-            }
         }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// Close-set kernel: the targets listed by the fast kernel, exact guard, one target per lane, fp64
-// second level.  Grid (kCloseBlocksX, kCloseSlices): workgroup (bx, y) takes target blocks bx,
-// bx + gridDim.x, ... of the list against source slice y; an empty list costs one scalar load.
-// Writes close_acc[y][k][slot]; scatter_close_kernel folds the slices into acc.
+// Close set (nbx_internal.h).  classify_close_kernel lists the shard's candidate targets (a coordinate
+// below kCloseCoord), refine_close_kernel keeps the ones that own a pair with 0 < r^2 < kBadR2 -- both
+// run once per position update.  close_set_path is executed by the EXTRA workgroups of a fast launch
+// (blockIdx.x < close_blocks, i.e. dispatched first in every slice row): workgroup (cx, y) takes blocks cx, cx + CX, ... of 256 listed targets
+// against source slice y with the exact compare-and-select guard, one target per lane, fp64 second
+// level, and writes close_acc[y][k][slot]; an empty list costs one scalar load.  The guarded work thus
+// rides along the main launch instead of trailing it at low occupancy.
 // -------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void accel_close_kernel(KArgs a) {
-    __shared__ float4 tile[2][kTile];
-    const unsigned tid = threadIdx.x;
-    const unsigned n = *a.close_counter;
-    const unsigned nblk = (n + 255u) / 256u;
+__global__ __launch_bounds__(256) void classify_close_kernel(KArgs a) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.count) return;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
-    const unsigned tiles_per_slice = (a.total_tiles + gridDim.y - 1) / gridDim.y;
+    const float x = tp[i], y = tp[(size_t)a.pad + i], z = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
+    if (in_close_set<D>(x, y, z)) {
+        const unsigned slot = atomicAdd(&a.counters[0], 1u);
+        a.cand_list[slot] = i;
+        a.cand_pos[slot] = x;
+        a.cand_pos[(size_t)a.pad + slot] = y;
+        if (D == 3) a.cand_pos[2 * (size_t)a.pad + slot] = z;
+    }
+}
 
+// Candidates against candidates: keep those with a partner at 0 < r^2 < kBadR2 (see nbx_internal.h).
+// Fixed grid, grid-stride over blocks of 256 candidates; the candidate positions stream through LDS.
+template <int D>
+__global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
+    __shared__ float tx[256], ty[256], tz[256];
+    const unsigned tid = threadIdx.x;
+    const unsigned n = a.counters[0];
+    const unsigned nblk = (n + 255u) / 256u;
+    const bool keep_all = n > kRefineLimit;
     for (unsigned tb = blockIdx.x; tb < nblk; tb += gridDim.x) {
         const unsigned slot = tb * 256u + tid;
         const bool valid = slot < n;
-        const unsigned i = a.close_list[valid ? slot : 0];
+        const unsigned ls = valid ? slot : 0;
+        const float x = a.cand_pos[ls], y = a.cand_pos[(size_t)a.pad + ls], z = (D == 3) ? a.cand_pos[2 * (size_t)a.pad + ls] : 0.0f;
+        bool bad = keep_all;
+        if (!keep_all) {
+            for (unsigned sb = 0; sb < nblk; ++sb) {
+                const unsigned j = sb * 256u + tid;
+                __syncthreads();
+                // out-of-range entries duplicate this lane's own position: r^2 = 0, never "bad"
+                tx[tid] = (j < n) ? a.cand_pos[j] : x;
+                ty[tid] = (j < n) ? a.cand_pos[(size_t)a.pad + j] : y;
+                tz[tid] = (D == 3 && j < n) ? a.cand_pos[2 * (size_t)a.pad + j] : z;
+                __syncthreads();
+                const unsigned lim = (n - sb * 256u < 256u) ? n - sb * 256u : 256u;
+                for (unsigned k = 0; k < lim; ++k) {
+                    const float dx = tx[k] - x, dy = ty[k] - y;
+                    float r2 = __builtin_fmaf(dy, dy, dx * dx);
+                    if (D == 3) { const float dz = tz[k] - z; r2 = __builtin_fmaf(dz, dz, r2); }
+                    bad = bad || (r2 > 0.0f && r2 < kBadR2);
+                }
+            }
+        }
+        if (valid && bad) {
+            const unsigned i = a.cand_list[slot];
+            const unsigned b = atomicAdd(&a.counters[1], 1u);
+            a.bad_list[b] = i;
+            a.bad_flag[i] = 1;
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile]) {
+    const unsigned tid = threadIdx.x;
+    const unsigned n = a.counters[1];
+    const unsigned nblk = (n + 255u) / 256u;
+    const unsigned cx = blockIdx.x, cstride = a.close_blocks;
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+
+    for (unsigned tb = cx; tb < nblk; tb += cstride) {
+        const unsigned slot = tb * 256u + tid;
+        const bool valid = slot < n;
+        const unsigned i = a.bad_list[valid ? slot : 0];
         const float ix = tp[i], iy = tp[(size_t)a.pad + i], iz = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
         double ox = 0.0, oy = 0.0, oz = 0.0;
 
-        unsigned t = blockIdx.y * tiles_per_slice;
-        unsigned t_end = t + tiles_per_slice;
+        unsigned t = blockIdx.y * a.tiles_per_split;
+        unsigned t_end = t + a.tiles_per_split;
         if (t_end > a.total_tiles) t_end = a.total_tiles;
         TileWalk w;
         w.seek(t, a.tiles_per_chunk);
@@ -382,16 +441,16 @@ __global__ __launch_bounds__(256) void accel_close_kernel(KArgs a) {
     }
 }
 
-// Fold the close-set kernel's slices (fp64, slice order) into acc: slice 0 receives the sum (added to
+// Fold the close-set path's slices (fp64, slice order) into acc: slice 0 receives the sum (added to
 // what a preceding LOCAL pass left there when accumulating), the other slices are zeroed.
 template <int D>
 __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
-    const unsigned n = *a.close_counter;
+    const unsigned n = a.counters[1];
     for (unsigned slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u) {
-        const unsigned i = a.close_list[slot];
+        const unsigned i = a.bad_list[slot];
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
-            for (int y = 0; y < kCloseSlices; ++y) v += (double)a.close_acc[((size_t)y * D + k) * a.pad + slot];
+            for (int y = 0; y < a.splits; ++y) v += (double)a.close_acc[((size_t)y * D + k) * a.pad + slot];
             float* __restrict__ dst = a.acc + (size_t)k * a.pad + i;
             if (a.accumulate) {
                 *dst = (float)((double)*dst + v);
@@ -506,12 +565,13 @@ const KernelVariant* NBX_CAT(variants_, NBX_FLAVOUR)(int* count) {
 }
 
 #ifdef NBX_EMIT_CLOSE_KERNELS
-// one copy of the close-set kernels (emitted by the scalar flavour's translation unit)
-void close_kernels(void (**k2)(KArgs), void (**k3)(KArgs), void (**s2)(KArgs), void (**s3)(KArgs)) {
-    *k2 = NBX_FLAVOUR::accel_close_kernel<2>;
-    *k3 = NBX_FLAVOUR::accel_close_kernel<3>;
-    *s2 = NBX_FLAVOUR::scatter_close_kernel<2>;
-    *s3 = NBX_FLAVOUR::scatter_close_kernel<3>;
+// one copy of the close-set helper kernels (emitted by the scalar flavour's translation unit)
+CloseKernels close_kernels() {
+    CloseKernels k;
+    k.classify[0] = NBX_FLAVOUR::classify_close_kernel<2>; k.classify[1] = NBX_FLAVOUR::classify_close_kernel<3>;
+    k.refine[0] = NBX_FLAVOUR::refine_close_kernel<2>;     k.refine[1] = NBX_FLAVOUR::refine_close_kernel<3>;
+    k.scatter[0] = NBX_FLAVOUR::scatter_close_kernel<2>;   k.scatter[1] = NBX_FLAVOUR::scatter_close_kernel<3>;
+    return k;
 }
 #endif
 

@@ -1,7 +1,7 @@
 // force_launch.hip -- host-side launcher of one force evaluation: merges the variant tables of the two
 // code-generation flavours of force_kernel.hip, checks launch shapes on the host, sizes the grids,
-// and for fast variants runs the close-set pipeline (counter reset -> fast kernel -> close-set kernel
-// -> scatter), all asynchronous on the caller's stream with no host read-back.
+// and for fast variants runs the close-set pipeline (classify when positions changed -> fast kernel
+// whose extra workgroups evaluate the close set -> scatter), all asynchronous on the caller's stream with no host read-back.
 #include "nbx_internal.h"
 
 #include <cstring>
@@ -13,10 +13,7 @@ namespace {
 struct Table {
     std::vector<KernelVariant> v;
     int def = 0, def_exact = 0;
-    void (*close2)(KArgs) = nullptr;
-    void (*close3)(KArgs) = nullptr;
-    void (*scat2)(KArgs) = nullptr;
-    void (*scat3)(KArgs) = nullptr;
+    CloseKernels ck;
     Table() {
         int n = 0;
         const KernelVariant* a = variants_scalar(&n);
@@ -27,7 +24,7 @@ struct Table {
             if (std::strcmp(v[i].name, NBX_DEFAULT_VARIANT) == 0) def = (int)i;
             if (std::strcmp(v[i].name, NBX_DEFAULT_EXACT_VARIANT) == 0) def_exact = (int)i;
         }
-        close_kernels(&close2, &close3, &scat2, &scat3);
+        ck = close_kernels();
     }
 };
 const Table& table() {
@@ -71,31 +68,41 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.chunk_skip = L.chunk_skip;
     a.accumulate = L.accumulate;
     a.splits = L.splits;
-    a.close_list = L.close_list;
-    a.close_counter = L.close_counter;
+    a.cand_list = L.cand_list;
+    a.cand_pos = L.cand_pos;
+    a.bad_list = L.bad_list;
+    a.bad_flag = L.bad_flag;
+    a.counters = L.counters;
     a.close_acc = L.close_acc;
     // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
-    if (V.fast && (!L.close_list || !L.close_counter || !L.close_acc)) return hipErrorInvalidValue;
+    if (V.fast && (!L.cand_list || !L.cand_pos || !L.bad_list || !L.bad_flag || !L.counters || !L.close_acc)) return hipErrorInvalidValue;
     if (V.max_tiles_per_slice > 0 && a.tiles_per_split > (unsigned)V.max_tiles_per_slice) return hipErrorInvalidValue;
 
-    if (V.fast) {
-        hipError_t e = hipMemsetAsync(L.close_counter, 0, sizeof(unsigned), stream);
-        if (e != hipSuccess) return e;
-    }
-    dim3 grid(L.pad / tgt_per_block, (unsigned)L.splits, 1), block(256, 1, 1);
+    a.close_blocks = V.fast ? (unsigned)kCloseBlocksX : 0u;
     hipError_t e = hipSuccess;
+    dim3 block(256, 1, 1);
+    const int di = dim - 2;
+    if (V.fast && !(L.close_list_valid && *L.close_list_valid)) {  // (re)build the bad-target list for these positions
+        if ((e = hipMemsetAsync(L.counters, 0, 2 * sizeof(unsigned), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(L.bad_flag, 0, L.pad, stream)) != hipSuccess) return e;
+        if (L.count) {
+            hipLaunchKernelGGL(table().ck.classify[di], dim3((L.count + 255u) / 256u, 1, 1), block, 0, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            hipLaunchKernelGGL(table().ck.refine[di], dim3(256, 1, 1), block, 0, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (L.close_list_valid) *L.close_list_valid = 1;
+    }
+    dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL((dim == 3) ? V.k3 : V.k2, grid, block, 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;
     if (!V.fast) return hipSuccess;
-    hipLaunchKernelGGL((dim == 3) ? table().close3 : table().close2, dim3(kCloseBlocksX, kCloseSlices, 1), block, 0, stream, a);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((dim == 3) ? table().scat3 : table().scat2, dim3(64, 1, 1), block, 0, stream, a);
+    hipLaunchKernelGGL(table().ck.scatter[di], dim3(64, 1, 1), block, 0, stream, a);
     return hipGetLastError();
 }
 

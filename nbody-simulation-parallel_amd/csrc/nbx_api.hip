@@ -58,9 +58,14 @@ struct nbx_ctx {
     float* acc = nullptr;
     int acc_splits_alloc = 0;
     // fast-path workspace (close-set pipeline) and its preconditions
-    unsigned* close_list = nullptr;
-    unsigned* close_counter = nullptr;
+    unsigned* cand_list = nullptr;
+    float* cand_pos = nullptr;
+    unsigned* bad_list = nullptr;
+    unsigned char* bad_flag = nullptr;
+    unsigned* counters = nullptr;
     float* close_acc = nullptr;
+    int close_splits_alloc = 0;
+    int close_list_valid = 0;   // the device list matches the positions in pos_all
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
     // boundary staging
@@ -91,11 +96,12 @@ int effective_variant(const nbx_ctx* c) {
     return v;
 }
 
-// Source slices: enough workgroups to give every SIMD several waves even for a small shard, and no
-// more tiles per slice than the kernel's fp32 second-level sums want.
+// Source slices: enough workgroups that the launch is many "waves" of workgroups deep (a grid that just
+// fills the chip once turns every extra workgroup into a full-length tail), and no more tiles per
+// slice than the kernel's fp32 second-level sums want.
 int auto_splits(const nbx_ctx* c, int variant) {
     const unsigned tgt_blocks = c->pad / (256u * (unsigned)variant_tpl(variant));
-    const unsigned want_blocks = (unsigned)c->num_cus * 4u;  // 4 workgroups (16 waves) per CU
+    const unsigned want_blocks = (unsigned)c->num_cus * 16u;  // >= 4 rounds of 4 workgroups per CU
     unsigned s = (want_blocks + tgt_blocks - 1) / tgt_blocks;
     const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
     const unsigned max_s = tiles / 8 ? tiles / 8 : 1;  // keep >= 8 tiles (2048 sources) per slice
@@ -123,10 +129,20 @@ int ensure_acc(nbx_ctx* c) {
         HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
         c->acc_splits_alloc = c->splits;
     }
-    if (variant_is_fast(c->variant) && !c->close_acc) {
-        HIP_TRY(hipMalloc((void**)&c->close_list, (size_t)c->pad * sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void**)&c->close_counter, sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void**)&c->close_acc, (size_t)kCloseSlices * c->dim * c->pad * sizeof(float)));
+    if (variant_is_fast(c->variant)) {
+        if (!c->cand_list) {
+            HIP_TRY(hipMalloc((void**)&c->cand_list, (size_t)c->pad * sizeof(unsigned)));
+            HIP_TRY(hipMalloc((void**)&c->cand_pos, (size_t)c->dim * c->pad * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&c->bad_list, (size_t)c->pad * sizeof(unsigned)));
+            HIP_TRY(hipMalloc((void**)&c->bad_flag, (size_t)c->pad));
+            HIP_TRY(hipMalloc((void**)&c->counters, 2 * sizeof(unsigned)));
+            c->close_list_valid = 0;
+        }
+        if (!(c->close_acc && c->close_splits_alloc >= c->splits)) {
+            if (c->close_acc) { HIP_TRY(hipFree(c->close_acc)); c->close_acc = nullptr; }
+            HIP_TRY(hipMalloc((void**)&c->close_acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
+            c->close_splits_alloc = c->splits;
+        }
     }
     return NBX_OK;
 }
@@ -222,8 +238,11 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->v64) (void)hipFree(c->v64);
     if (c->m64) (void)hipFree(c->m64);
     if (c->acc) (void)hipFree(c->acc);
-    if (c->close_list) (void)hipFree(c->close_list);
-    if (c->close_counter) (void)hipFree(c->close_counter);
+    if (c->cand_list) (void)hipFree(c->cand_list);
+    if (c->cand_pos) (void)hipFree(c->cand_pos);
+    if (c->bad_list) (void)hipFree(c->bad_list);
+    if (c->bad_flag) (void)hipFree(c->bad_flag);
+    if (c->counters) (void)hipFree(c->counters);
     if (c->close_acc) (void)hipFree(c->close_acc);
     if (c->stage) (void)hipFree(c->stage);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
@@ -304,6 +323,7 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
     c->uploaded = true;
     c->have_accel = false;
+    c->close_list_valid = 0;
     return NBX_OK;
 }
 
@@ -345,7 +365,9 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     AccelLaunch L;
     L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
-    L.close_list = c->close_list; L.close_counter = c->close_counter; L.close_acc = c->close_acc;
+    L.cand_list = c->cand_list; L.cand_pos = c->cand_pos; L.bad_list = c->bad_list; L.bad_flag = c->bad_flag;
+    L.counters = c->counters; L.close_acc = c->close_acc;
+    L.close_list_valid = &c->close_list_valid;
     L.chunk_skip = INT_MAX; L.accumulate = 0;
     if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
@@ -371,6 +393,7 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
     k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
     HIP_TRY(launch_kick_drift(k, c->stream));
     c->have_accel = false;
+    c->close_list_valid = 0;  // positions moved
     return NBX_OK;
 }
 

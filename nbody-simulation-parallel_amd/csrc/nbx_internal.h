@@ -21,20 +21,27 @@ static_assert((double)kR2SkipF >= 1e-10, "fp32 threshold must not round below th
 
 // ---- close-pair bookkeeping of the fast force path (force_kernel.hip) --------------------------------
 // The fast kernel carries no per-pair guard: it biases r^2 by kTiny so that coincident bodies (d = 0)
-// contribute exactly 0 and 1/r^2 stays finite.  That is exact unless a pair has 0 < r^2 < ~1e-6.  Two
-// DISTINCT fp32 coordinates a, b differ by at least the fp32 spacing at min(|a|,|b|); if every
-// coordinate of a target is >= kCloseCoord = 8192 in magnitude, any source that differs from it in
-// some coordinate is at least ulp(4096..8192) = 4.88e-4 away in that coordinate, i.e. r^2 >= 2.38e-7,
-// where the bias kTiny = 2^-47 moves r^2 by at most half a unit roundoff (2^-25).  Targets with a
-// coordinate below kCloseCoord ("close set", ~0.25 % of the reference's uniform bodies) are left
-// unwritten by the fast kernel, listed, and evaluated by accel_close_kernel with the exact
-// compare-and-select guard.  The result therefore has the reference's skip semantics for every pair.
+// contribute exactly 0 and 1/r^2 stays finite.  That is exact unless a target has a source with
+// 0 < r^2 < kBadR2 (there the bias, or the reference's skip rule r^2 < 1e-10, would matter; for
+// r^2 >= kBadR2 = 1e-6 the bias kTiny = 2^-47 moves r^2 by < 1e-8 relative, far below half an ulp).
+// Such "bad" targets are found exactly, once per position update, in two cheap steps:
+//  1. candidates: two DISTINCT fp32 coordinates a, b differ by at least the fp32 spacing at
+//     min(|a|,|b|), so a pair with 0 < r^2 < 1e-6 (every |d_k| < 1e-3, some d_k != 0) has both members
+//     with a coordinate of magnitude < 2^14 in that dimension.  classify_close_kernel lists the
+//     targets with any |coordinate| < kCloseCoord = 16384 (0.5 % of the reference's uniform bodies);
+//  2. refine_close_kernel checks the candidates against each other (all-pairs over the small list,
+//     the same fp32 r^2) and keeps those that really have a partner with 0 < r^2 < kBadR2 -- almost
+//     always none.  Above kRefineLimit candidates it keeps them all.
+// Bad targets are flagged (the fast kernel does not store them) and evaluated with the exact
+// compare-and-select guard by extra workgroups of the same launch (close_set_path), then scattered
+// into acc.  The result therefore has the reference's skip semantics for every pair.
 constexpr float kTiny = 0x1p-47f;          // 7.1e-15
-constexpr float kCloseCoord = 8192.0f;
+constexpr float kCloseCoord = 16384.0f;
+constexpr float kBadR2 = 1.0e-6f;
+constexpr unsigned kRefineLimit = 131072;  // candidates beyond this are all treated as bad (O(n^2) check avoided)
 // m / (kTiny^2) must stay finite in fp32 for a coincident source: masses above this force the exact path.
 constexpr double kFastMaxMass = 1.0e10;
-constexpr int kCloseSlices = 32;           // source slices of the close-set kernel
-constexpr int kCloseBlocksX = 64;          // target-block lanes of the close-set kernel's grid
+constexpr int kCloseBlocksX = 32;          // extra workgroups per source slice that a fast launch adds for bad targets
 
 // How one force evaluation walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
 struct AccelLaunch {
@@ -51,9 +58,13 @@ struct AccelLaunch {
     int accumulate;      // 0: acc = result, 1: acc += result
     int variant;         // force-kernel variant id
     // workspace of the fast path (may be null for exact variants)
-    unsigned* close_list;     // [pad] target indices of the close set
-    unsigned* close_counter;  // [1]
-    float* close_acc;         // [kCloseSlices][dim][pad]
+    unsigned* cand_list;      // [pad] candidate target indices
+    float* cand_pos;          // [dim][pad] their positions, compacted
+    unsigned* bad_list;       // [pad] targets that own a pair with 0 < r^2 < kBadR2
+    unsigned char* bad_flag;  // [pad] 1 for listed targets
+    unsigned* counters;       // [0] = candidates, [1] = bad targets
+    float* close_acc;         // [splits][dim][pad]
+    int* close_list_valid;    // host flag owned by the context: lists match the current positions
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -71,8 +82,12 @@ struct KArgs {
     int tgt_chunk, chunk_first, chunk_skip;
     int accumulate;
     int splits;
-    unsigned* __restrict__ close_list;
-    unsigned* __restrict__ close_counter;
+    unsigned close_blocks;     // fast kernels: workgroups with blockIdx.x < close_blocks run close_set_path
+    unsigned* __restrict__ cand_list;
+    float* __restrict__ cand_pos;
+    unsigned* __restrict__ bad_list;
+    unsigned char* __restrict__ bad_flag;
+    unsigned* __restrict__ counters;
     float* __restrict__ close_acc;
 };
 
@@ -87,7 +102,8 @@ struct KernelVariant {
 // force_kernel.hip, compiled once per code-generation flavour
 const KernelVariant* variants_slp(int* count);
 const KernelVariant* variants_scalar(int* count);
-void close_kernels(void (**k2)(KArgs), void (**k3)(KArgs), void (**s2)(KArgs), void (**s3)(KArgs));
+struct CloseKernels { void (*classify[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); };  // [0]: D=2, [1]: D=3
+CloseKernels close_kernels();
 
 // force_launch.hip
 hipError_t launch_accel(int dim, const AccelLaunch& a, hipStream_t stream);
