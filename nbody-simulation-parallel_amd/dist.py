@@ -66,6 +66,18 @@ class HipShardBackend:
         if self.layout.n_shards == 1:
             return None
         self.comm_stream.wait_stream(self.compute_stream)
+        if dist.get_backend(group) != "nccl":
+            # Rehearsal transport (gloo has no device collectives): stage the own chunk through host
+            # memory.  Same buffers, same ordering; only the wire differs.  Not used on a multi-GPU node.
+            with torch.cuda.stream(self.comm_stream):
+                mine = self.pos_all[self.layout.shard].to("cpu", non_blocking=False).reshape(-1)
+            allc = torch.empty((self.layout.n_shards, mine.numel()), dtype=torch.float32)
+            dist.all_gather_into_tensor(allc.view(-1), mine, group=group)
+            with torch.cuda.stream(self.comm_stream):
+                for g in range(self.layout.n_shards):
+                    if g != self.layout.shard:
+                        self.pos_all[g].view(-1).copy_(allc[g].to(self.device, non_blocking=False))
+            return "staged"
         with torch.cuda.stream(self.comm_stream):
             return dist.all_gather_into_tensor(self.pos_all.view(-1), self.pos_all[self.layout.shard].view(-1),
                                                group=group, async_op=True)
@@ -73,8 +85,9 @@ class HipShardBackend:
     def finish_exchange(self, work):
         if work is None:
             return
-        with torch.cuda.stream(self.comm_stream):
-            work.wait()
+        if work != "staged":
+            with torch.cuda.stream(self.comm_stream):
+                work.wait()
         self.compute_stream.wait_stream(self.comm_stream)
 
     # -- results --
@@ -140,7 +153,7 @@ class ShardedNBody:
         padded[: hi - lo] = mine
         use_cuda = dist.get_backend(self.group) == "nccl"
         if use_cuda:
-            padded = padded.cuda()
+            padded = padded.cuda()  # the current device was set by the back end
         allb = torch.zeros((self.layout.n_shards, self.layout.shard_len, width), dtype=torch.float64, device=padded.device)
         dist.all_gather_into_tensor(allb.view(-1), padded.view(-1), group=self.group)
         allb = allb.cpu().numpy()

@@ -1,0 +1,78 @@
+"""GPU: the one-process-per-rank path end to end on the single-GPU box: two ranks share cuda:0, each
+owns one shard through HipShardBackend (HIP kernels, torch streams, the library launching on the torch
+compute stream, torch-owned exchange buffers).  The position exchange is staged over gloo here because a
+single device cannot host two RCCL ranks; on a multi-GPU node the same code takes the
+all_gather_into_tensor(nccl) branch of HipShardBackend.start_exchange."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nbody_amd as nbx
+        bodies = nbx.uniform_bodies(n, dim, 77)
+        bodies[:, :dim] = bodies[:, :dim].astype(np.float32)
+        bodies[:, -1] = bodies[:, -1].astype(np.float32)
+        G = nbx.REFERENCE_G * gscale
+        system = nbx.package.dist.make_hip_system(bodies, dim, rank=rank, world_size=world, device_index=0)
+        system.compute_forces()
+        system.be.synchronize()
+        f0 = system.forces(G)
+        system.step(dt, G, steps)
+        system.be.synchronize()
+        final = system.gather_bodies(bodies)
+        lo, hi = system.layout.bounds()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi,
+                 tuning=np.array(system.be.ctx.effective_tuning()[0]))
+        system.be.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,dim", [(2, 6000, 3), (3, 5001, 2)])
+def test_two_ranks_one_gpu(tmp_path, oracle, world, n, dim):
+    from oracle_lib import assert_force_parity
+    steps, dt, gscale = 3, 2.0, 1e24
+    mp.spawn(_worker, args=(world, _free_port(), n, dim, steps, dt, gscale, str(tmp_path)), nprocs=world, join=True)
+    bodies = oracle.round_inputs_to_f32(oracle.generate(77, n, dim))
+    ref_f0 = oracle.brute_force_seq(bodies) * gscale
+    S = oracle.force_magnitude_sums(bodies) * gscale
+    ref = bodies.copy()
+    for _ in range(steps):
+        f = oracle.brute_force_seq(oracle.round_inputs_to_f32(ref)) * gscale
+        oracle.update_body_velocities(ref, np.ascontiguousarray(f), dt)
+        oracle.update_body_positions(ref, dt)
+    finals = []
+    for r in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert_force_parity(z["f0"], ref_f0[lo:hi], S[lo:hi], f"rank {r} forces")
+        finals.append(z["final"])
+    for fin in finals[1:]:
+        assert np.array_equal(fin, finals[0])
+    d = dim
+    moved = np.abs(ref[:, d:2 * d] - bodies[:, d:2 * d]).max()
+    assert moved > 1e-6
+    assert np.allclose(finals[0][:, d:2 * d], ref[:, d:2 * d], rtol=0, atol=3e-5 * moved)
+    assert np.allclose(finals[0][:, :d], ref[:, :d], rtol=1e-9, atol=0)
