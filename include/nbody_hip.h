@@ -131,6 +131,15 @@ int nbx_ctx_get_accel(nbx_ctx* ctx, float* accel_out);
  * Body<dim> array (only entries [shard*shard_len, ...) are touched).  Synchronises the stream. */
 int nbx_ctx_download_bodies(nbx_ctx* ctx, void* bodies, size_t body_stride_bytes);
 
+/* Energy diagnostic (for energy-drift checks; the reference has none -- SURVEY 5): this shard's share of
+ *   kinetic   = sum_i m_i |v_i|^2 / 2                       (fp64 state)
+ *   potential = sum_i (G m_i / 4) sum_{j != i} m_j / r_ij^2   (fp32 pair terms, fp64 sums, pairs with
+ *               r^2 < 1e-10 skipped) -- summed over all shards this is U = sum_{i<j} G m_i m_j / (2 r^2),
+ * the potential whose gradient is the reference's force law (methods.cpp:21-37), so kinetic + potential is
+ * what a symplectic kick/drift conserves.  Uses the positions currently in the exchange buffer for the
+ * sources.  One O(N^2/G) kernel; synchronises the stream. */
+int nbx_ctx_energy(nbx_ctx* ctx, double G, double* kinetic, double* potential);
+
 int nbx_ctx_synchronize(nbx_ctx* ctx);
 
 /* Tuning knobs.  source_splits: number of slices the source loop is cut into (0 = automatic, else a

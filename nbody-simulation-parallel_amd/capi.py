@@ -46,6 +46,7 @@ ABI = [
     ("nbx_ctx_get_forces", _i, [_vp, _d, _vp]),
     ("nbx_ctx_get_accel", _i, [_vp, _vp]),
     ("nbx_ctx_download_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_ctx_energy", _i, [_vp, _d, _pd, _pd]),
     ("nbx_ctx_synchronize", _i, [_vp]),
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
@@ -228,6 +229,12 @@ class Context:
         if dim != self.dim or b.shape[0] != self.n_total:
             raise ValueError("bodies shape does not match the context")
         self._ck(self.lib.nbx_ctx_download_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_ctx_download_bodies")
+
+    def energy(self, G: float = REFERENCE_G) -> Tuple[float, float]:
+        """(kinetic, potential) share of this shard under the potential that matches the reference law."""
+        ke, pe = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._ck(self.lib.nbx_ctx_energy(self.h, G, ctypes.byref(ke), ctypes.byref(pe)), "nbx_ctx_energy")
+        return ke.value, pe.value
 
     def synchronize(self):
         self._ck(self.lib.nbx_ctx_synchronize(self.h), "nbx_ctx_synchronize")

@@ -463,6 +463,70 @@ __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Potential kernel (diagnostic for energy-drift checks, BASELINE config 5): phi_i = sum_j m_j / r_ij^2
+// over the selected sources with the reference's skip rule, so that the energy matching the reference
+// law is U = sum_i (G m_i / 4) phi_i  (F = -grad U for U = sum_{i<j} G m_i m_j / (2 r^2)).
+// Same tiling as the exact force kernel, two targets per lane, fp64 second level; 9 VALU per pair.
+// Writes phi[slice][i] (fp32), summed over slices in fp64 by export_energy_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
+    constexpr int TPL = 2;
+    __shared__ float4 tile[2][kTile];
+    const unsigned tid = threadIdx.x;
+    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+    float ix[TPL], iy[TPL], iz[TPL];
+    double o[TPL];
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {
+        const unsigned i = tgt0 + q * 256u;
+        ix[q] = tp[i];
+        iy[q] = tp[(size_t)a.pad + i];
+        iz[q] = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
+        o[q] = 0.0;
+    }
+    unsigned t = blockIdx.y * a.tiles_per_split;
+    unsigned t_end = t + a.tiles_per_split;
+    if (t_end > a.total_tiles) t_end = a.total_tiles;
+    TileWalk w;
+    w.seek(t, a.tiles_per_chunk);
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < t_end) nxt = load_source<D>(a, w, tid);
+    int buf = 0;
+    for (; t < t_end; ++t) {
+        tile[buf][tid] = nxt;
+        __syncthreads();
+        if (t + 1 < t_end) {
+            w.next(a.tiles_per_chunk);
+            nxt = load_source<D>(a, w, tid);
+        }
+        float p[TPL];
+#pragma unroll
+        for (int q = 0; q < TPL; ++q) p[q] = 0.0f;
+        const float4* __restrict__ cur = tile[buf];
+#pragma unroll 8
+        for (int j = 0; j < kTile; ++j) {
+            const float4 s = cur[j];
+#pragma unroll
+            for (int q = 0; q < TPL; ++q) {
+                const float dx = s.x - ix[q], dy = s.y - iy[q];
+                float r2 = __builtin_fmaf(dy, dy, dx * dx);
+                if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
+                const float r2g = (r2 < kR2SkipF) ? __builtin_inff() : r2;
+                p[q] = __builtin_fmaf(s.w, __builtin_amdgcn_rcpf(r2g), p[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TPL; ++q) o[q] += (double)p[q];
+        buf ^= 1;
+    }
+    float* __restrict__ out = a.acc + (size_t)blockIdx.y * a.pad;  // a.acc = phi[slice][pad] here
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) out[tgt0 + q * 256u] = (float)o[q];
+}
+
+// -------------------------------------------------------------------------------------------------
 // SMEM variant (exact): no LDS, no barriers.  Source arrays are read with wave-uniform addresses,
 // which hipcc turns into s_load_dwordx8 through the scalar cache; x/y/z/m of a source are then SGPR
 // operands of the VALU instructions.  Kept for A/B: an SGPR source operand slows v_fma_f32 on gfx950.
@@ -571,6 +635,7 @@ CloseKernels close_kernels() {
     k.classify[0] = NBX_FLAVOUR::classify_close_kernel<2>; k.classify[1] = NBX_FLAVOUR::classify_close_kernel<3>;
     k.refine[0] = NBX_FLAVOUR::refine_close_kernel<2>;     k.refine[1] = NBX_FLAVOUR::refine_close_kernel<3>;
     k.scatter[0] = NBX_FLAVOUR::scatter_close_kernel<2>;   k.scatter[1] = NBX_FLAVOUR::scatter_close_kernel<3>;
+    k.potential[0] = NBX_FLAVOUR::potential_kernel<2>;     k.potential[1] = NBX_FLAVOUR::potential_kernel<3>;
     return k;
 }
 #endif

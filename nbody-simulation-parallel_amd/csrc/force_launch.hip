@@ -106,4 +106,24 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launch_potential(int dim, const AccelLaunch& L, hipStream_t stream) {
+    if ((dim != 2 && dim != 3) || L.pad == 0 || L.pad % kPadQuantum != 0 || L.splits < 1 || L.vchunks < 1)
+        return hipErrorInvalidValue;
+    KArgs a = {};
+    a.pos_all = L.pos_all;
+    a.mass_all = L.mass_all;
+    a.acc = L.acc;
+    a.pad = L.pad;
+    a.count = L.count;
+    a.tiles_per_chunk = L.pad / kTile;
+    a.total_tiles = (unsigned)L.vchunks * a.tiles_per_chunk;
+    a.tiles_per_split = (a.total_tiles + (unsigned)L.splits - 1) / (unsigned)L.splits;
+    a.tgt_chunk = L.tgt_chunk;
+    a.chunk_first = L.chunk_first;
+    a.chunk_skip = L.chunk_skip;
+    a.splits = L.splits;
+    hipLaunchKernelGGL(table().ck.potential[dim - 2], dim3(L.pad / 512u, (unsigned)L.splits, 1), dim3(256, 1, 1), 0, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace nbx

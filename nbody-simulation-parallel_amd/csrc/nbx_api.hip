@@ -38,6 +38,7 @@ int fail(int code, const char* msg) {
 
 constexpr int kEventPairs = 512;
 constexpr int kMaxSplits = 256;
+constexpr int kPhiSlices = 16;
 
 }  // namespace
 
@@ -65,6 +66,7 @@ struct nbx_ctx {
     unsigned* counters = nullptr;
     float* close_acc = nullptr;
     int close_splits_alloc = 0;
+    float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     int close_list_valid = 0;   // the device list matches the positions in pos_all
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
@@ -244,6 +246,7 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->bad_flag) (void)hipFree(c->bad_flag);
     if (c->counters) (void)hipFree(c->counters);
     if (c->close_acc) (void)hipFree(c->close_acc);
+    if (c->phi) (void)hipFree(c->phi);
     if (c->stage) (void)hipFree(c->stage);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
@@ -457,6 +460,31 @@ int nbx_ctx_download_bodies(nbx_ctx* c, void* bodies, size_t stride_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     char* base = (char*)bodies + (size_t)c->shard * c->shard_len * stride_bytes;
     for (size_t l = 0; l < c->count; ++l) std::memcpy(base + l * stride_bytes, &host[l * w], w * sizeof(double));
+    return NBX_OK;
+}
+
+int nbx_ctx_energy(nbx_ctx* c, double G, double* kinetic, double* potential) {
+    if (!c || !kinetic || !potential) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "nothing uploaded");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->phi) HIP_TRY(hipMalloc((void**)&c->phi, (size_t)kPhiSlices * c->pad * sizeof(float)));
+    AccelLaunch L = {};
+    L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->phi; L.pad = c->pad; L.count = (unsigned)c->count;
+    L.tgt_chunk = c->shard; L.chunk_first = 0; L.vchunks = c->n_shards; L.chunk_skip = INT_MAX; L.splits = kPhiSlices;
+    HIP_TRY(launch_potential(c->dim, L, c->stream));
+    const size_t bytes = 2 * c->count * sizeof(double);
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    HIP_TRY(launch_export_energy(c->phi, kPhiSlices, c->dim, c->pad, c->count, G, c->v64, c->m64, c->stage, c->stream));
+    std::vector<double> host;
+    try { host.resize(2 * c->count); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
+    if (bytes) HIP_TRY(hipMemcpyAsync(host.data(), c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    long double ke = 0.0L, pe = 0.0L;  // body order: deterministic
+    for (size_t l = 0; l < c->count; ++l) { ke += host[l]; pe += host[c->count + l]; }
+    *kinetic = (double)ke;
+    *potential = (double)pe;
     return NBX_OK;
 }
 

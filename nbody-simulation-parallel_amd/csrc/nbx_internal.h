@@ -102,11 +102,13 @@ struct KernelVariant {
 // force_kernel.hip, compiled once per code-generation flavour
 const KernelVariant* variants_slp(int* count);
 const KernelVariant* variants_scalar(int* count);
-struct CloseKernels { void (*classify[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); };  // [0]: D=2, [1]: D=3
+struct CloseKernels { void (*classify[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
 // force_launch.hip
 hipError_t launch_accel(int dim, const AccelLaunch& a, hipStream_t stream);
+// phi[splits][pad] = sum_j m_j / r^2 over ALL chunks (L.acc points at the phi buffer; L.splits slices)
+hipError_t launch_potential(int dim, const AccelLaunch& a, hipStream_t stream);
 int num_variants();
 const char* variant_name(int variant);
 int variant_tpl(int variant);
@@ -149,6 +151,9 @@ hipError_t launch_export_forces(const float* acc, int splits, int dim, unsigned 
 // accel_out: SoA float[dim][count] on the device (splits summed in fp64, rounded once)
 hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned pad, size_t count,
                                float* accel_out, hipStream_t stream);
+// energy_out: double[2][count]: per-body kinetic m v^2 / 2 and potential (G m / 4) * sum_slices phi
+hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned pad, size_t count, double G,
+                                const double* v64, const double* m64, double* energy_out, hipStream_t stream);
 // state_out: AoS double[count][2*dim] = position then velocity
 hipError_t launch_export_state(const double* x64, const double* v64, int dim, unsigned pad, size_t count,
                                double* state_out, hipStream_t stream);

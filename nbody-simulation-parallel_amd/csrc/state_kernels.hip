@@ -88,6 +88,23 @@ __global__ __launch_bounds__(256) void export_state_kernel(const double* __restr
     }
 }
 
+// Per-body energies for the reference law: kinetic m v^2 / 2 and potential (G m / 4) * phi,
+// phi = sum over slices of potential_kernel's output (fp64, slice order).
+__global__ __launch_bounds__(256) void export_energy_kernel(const float* __restrict__ phi, int splits, int dim,
+                                                            unsigned pad, size_t count, double G,
+                                                            const double* __restrict__ v64,
+                                                            const double* __restrict__ m64, double* __restrict__ out) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= count) return;
+    double p = 0.0;
+    for (int s = 0; s < splits; ++s) p += (double)phi[(size_t)s * pad + l];
+    double v2 = 0.0;
+    for (int k = 0; k < dim; ++k) { const double v = v64[(size_t)k * pad + l]; v2 += v * v; }
+    const double m = m64[l];
+    out[l] = 0.5 * m * v2;
+    out[count + l] = 0.25 * G * m * p;
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -118,6 +135,14 @@ hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned p
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(export_accel_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, acc, splits, dim, pad,
                        count, accel_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned pad, size_t count, double G,
+                                const double* v64, const double* m64, double* energy_out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(export_energy_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, phi, splits, dim, pad, count,
+                       G, v64, m64, energy_out);
     return hipGetLastError();
 }
 

@@ -94,6 +94,9 @@ class HipShardBackend:
     def forces(self, G: float) -> np.ndarray:
         return self.ctx.forces(G)
 
+    def energy(self, G: float):
+        return self.ctx.energy(G)
+
     def download_into(self, bodies: np.ndarray):
         self.ctx.download(bodies)
 
@@ -139,6 +142,20 @@ class ShardedNBody:
 
     def forces(self, G: float = capi.REFERENCE_G) -> np.ndarray:
         return self.be.forces(G)
+
+    def energy(self, G: float = capi.REFERENCE_G):
+        """(kinetic, potential) of the WHOLE system: refresh every rank's source copy, evaluate the
+        shard's share on the device, sum over ranks."""
+        work = self.be.start_exchange(self.group)
+        self.be.finish_exchange(work)
+        ke, pe = self.be.energy(G)
+        if self.layout.n_shards > 1:
+            t = torch.tensor([ke, pe], dtype=torch.float64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            ke, pe = float(t[0]), float(t[1])
+        return ke, pe
 
     def gather_bodies(self, bodies: np.ndarray) -> np.ndarray:
         """Assemble the full Body<D> array on every rank from the ranks' shards (host side, fp64)."""

@@ -74,3 +74,15 @@ class CpuShardDouble:
 
     def synchronize(self):
         pass
+
+    # energy share of this shard (same definition as nbx_ctx_energy)
+    def energy(self, G):
+        L = self.layout
+        tgt = self.pos_all[L.shard, :, : L.count].numpy().T.astype(np.float64)
+        phi = np.zeros(L.count)
+        for g in range(L.n_shards):
+            src = self.pos_all[g].numpy().T.astype(np.float64)
+            m = self.mass_all[g].numpy().astype(np.float64)
+            r2 = ((src[None, :, :] - tgt[:, None, :]) ** 2).sum(-1)
+            phi += np.where(r2 < 1e-10, 0.0, m[None, :] / np.where(r2 < 1e-10, 1.0, r2)).sum(1)
+        return float((0.5 * self.m * (self.v ** 2).sum(1)).sum()), float((0.25 * G * self.m * phi).sum())

@@ -41,8 +41,11 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         f0 = sysm.forces(o.G * gscale)
         sysm.step(dt, o.G * gscale, steps)
         final = sysm.gather_bodies(bodies)
+        ncalls = len(be.calls)
+        ke, pe = sysm.energy(o.G * gscale)
         lo, hi = layout.bounds()
-        np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi, calls=np.array(be.calls))
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi, calls=np.array(be.calls[:ncalls]),
+                 energy=np.array([ke, pe]))
     finally:
         dist.destroy_process_group()
 
@@ -74,6 +77,14 @@ def test_sharded_steps_match_oracle(tmp_path, oracle, world, n, dim):
         assert calls == per + (per + ["kick_drift"]) * steps, "exchange must precede the local pass every step"
     for fin in finals[1:]:
         assert np.array_equal(fin, finals[0]), "every rank must assemble the same state"
+    # whole-system energy, identical on every rank, equals the oracle's on the final state
+    if n > 1:
+        fin32 = oracle.round_inputs_to_f32(finals[0])
+        fin32[:, dim:2 * dim] = finals[0][:, dim:2 * dim]
+        ke_ref, pe_ref = oracle.energy(fin32)
+        for r in range(world):
+            e = np.load(os.path.join(tmp_path, f"rank{r}.npz"))["energy"]
+            assert abs(e[0] - ke_ref) <= 1e-12 * abs(ke_ref) and abs(e[1] - pe_ref * gscale) <= 1e-9 * abs(pe_ref * gscale)
     d = dim
     if n > 1:
         moved = np.abs(ref[:, d:2 * d] - bodies[:, d:2 * d]).max()
