@@ -6,6 +6,7 @@
 
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -39,6 +40,7 @@ int fail(int code, const char* msg) {
 constexpr int kEventPairs = 512;
 constexpr int kMaxSplits = 256;
 constexpr int kPhiSlices = 16;
+constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from this many steps on
 
 }  // namespace
 
@@ -67,6 +69,13 @@ struct nbx_ctx {
     float* close_acc = nullptr;
     int close_splits_alloc = 0;
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
+    // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
+    hipGraphExec_t step_exec = nullptr;
+    double graph_G = 0.0, graph_dt = 0.0;
+    int graph_variant = -1, graph_splits = 0;
+    hipStream_t graph_stream = nullptr;
+    bool capturing = false;
+    bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
     int close_list_valid = 0;   // the device list matches the positions in pos_all
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
@@ -106,7 +115,7 @@ int auto_splits(const nbx_ctx* c, int variant) {
     const unsigned want_blocks = (unsigned)c->num_cus * 16u;  // >= 4 rounds of 4 workgroups per CU
     unsigned s = (want_blocks + tgt_blocks - 1) / tgt_blocks;
     const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
-    const unsigned max_s = tiles / 8 ? tiles / 8 : 1;  // keep >= 8 tiles (2048 sources) per slice
+    const unsigned max_s = tiles / 2 ? tiles / 2 : 1;  // keep >= 2 tiles (512 sources) per slice
     if (s > max_s) s = max_s;
     const int cap = variant_max_tiles_per_slice(variant);
     if (cap > 0) {
@@ -209,6 +218,7 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     c->pad = (unsigned)pad;
     c->variant = default_variant();
     c->variant_req = -1;
+    { const char* e = std::getenv("NBODY_HIP_NO_GRAPHS"); c->no_graphs = e && *e && *e != '0'; }
 #define CTX_TRY(expr)                                                            \
     do {                                                                         \
         hipError_t e_ = (expr);                                                  \
@@ -247,6 +257,7 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->counters) (void)hipFree(c->counters);
     if (c->close_acc) (void)hipFree(c->close_acc);
     if (c->phi) (void)hipFree(c->phi);
+    if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);
     if (c->stage) (void)hipFree(c->stage);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
@@ -376,7 +387,7 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
     else { L.chunk_first = 0; L.vchunks = c->n_shards - 1; L.chunk_skip = c->shard; L.accumulate = 1; }
     if (L.vchunks == 0) return NBX_OK;  // REMOTE with a single shard: nothing to add
-    const bool timed = c->ev_used < kEventPairs;
+    const bool timed = !c->capturing && c->ev_used < kEventPairs;
     if (timed) { L.ev_start = c->ev0[c->ev_used]; L.ev_stop = c->ev1[c->ev_used]; }
     HIP_TRY(launch_accel(c->dim, L, c->stream));
     if (timed) ++c->ev_used;
@@ -400,11 +411,50 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
     return NBX_OK;
 }
 
+namespace {
+// Capture one step on the context's stream into an executable graph (launch-bound regime: seven
+// launches per step cost ~7 % at N = 65,536).  Returns false -- leaving no capture open -- if anything
+// about capture is unavailable; the caller then steps eagerly.
+bool capture_step(nbx_ctx* c, double G, double dt) {
+    if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
+        c->graph_splits == c->splits && c->graph_stream == c->stream)
+        return true;
+    if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+    c->capturing = true;
+    c->close_list_valid = 0;
+    int rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
+    if (!rc) rc = nbx_ctx_kick_drift(c, G, dt);
+    c->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return false; }
+    const hipError_t ei = hipGraphInstantiate(&c->step_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
+    c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
+    return true;
+}
+}  // namespace
+
 int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
     if (c->n_shards != 1) return fail(NBX_ERR_STATE, "nbx_ctx_step drives single-shard contexts only");
     if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps < 0");
-    for (int s = 0; s < nsteps; ++s) {
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies before stepping");
+    int s = 0;
+    if (nsteps >= kGraphMinSteps && !c->no_graphs) {
+        int rc = set_device(c);
+        if (rc) return rc;
+        rc = ensure_acc(c);  // every allocation happens before capture
+        if (rc) return rc;
+        if (capture_step(c, G, dt)) {
+            for (; s < nsteps; ++s) HIP_TRY(hipGraphLaunch(c->step_exec, c->stream));
+            c->have_accel = false;
+            c->close_list_valid = 0;
+        }
+    }
+    for (; s < nsteps; ++s) {
         int rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
         if (rc) return rc;
         rc = nbx_ctx_kick_drift(c, G, dt);

@@ -182,6 +182,30 @@ def test_context_step_by_step_equals_one_shot(nbx, oracle):
     assert np.array_equal(one, two)
 
 
+def test_graph_replayed_steps_equal_eager_steps(nbx, oracle):
+    """nbx_ctx_step captures one step into a hipGraph from 4 steps on; the replay must be bit-identical to
+    launching the same kernels one by one."""
+    for n, dim in ((5000, 3), (700, 2)):
+        b = _oracle_inputs(oracle, 46, n, dim)
+        b[:, :dim] = b[:, :dim] / 50.0           # pull part of the system into the candidate region
+        b = oracle.round_inputs_to_f32(b)
+        eager, graph = b.copy(), b.copy()
+        Gs = oracle.G * 1e22
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            for _ in range(12):
+                c.compute_accel()
+                c.kick_drift(1.5, Gs)
+            c.download(eager)
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.step(1.5, 7, Gs)
+            c.step(1.5, 5, Gs)                   # second call reuses the instantiated graph
+            c.download(graph)
+        assert np.array_equal(eager, graph)
+        assert np.abs(eager[:, dim:2 * dim] - b[:, dim:2 * dim]).max() > 0
+
+
 def test_wrong_order_is_an_error(nbx, oracle):
     with nbx.Context(16, 3) as c:
         with pytest.raises(nbx.NbxError):
