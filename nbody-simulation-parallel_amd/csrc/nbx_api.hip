@@ -115,7 +115,11 @@ int auto_splits(const nbx_ctx* c, int variant) {
     const unsigned want_blocks = (unsigned)c->num_cus * 16u;  // >= 4 rounds of 4 workgroups per CU
     unsigned s = (want_blocks + tgt_blocks - 1) / tgt_blocks;
     const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
-    const unsigned max_s = tiles / 2 ? tiles / 2 : 1;  // keep >= 2 tiles (512 sources) per slice
+    // a slice should keep >= 8 tiles (2048 sources) so its prologue/epilogue stays small; only when that
+    // leaves the chip under-filled (< 4 workgroups per CU) are slices cut down to 2 tiles
+    unsigned max_s = tiles / 8 ? tiles / 8 : 1;
+    const unsigned fill = ((unsigned)c->num_cus * 4u + tgt_blocks - 1) / tgt_blocks;
+    if (max_s < fill) max_s = fill < (tiles / 2 ? tiles / 2 : 1) ? fill : (tiles / 2 ? tiles / 2 : 1);
     if (s > max_s) s = max_s;
     const int cap = variant_max_tiles_per_slice(variant);
     if (cap > 0) {

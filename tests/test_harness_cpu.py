@@ -71,3 +71,18 @@ def test_cli_validation_and_gates(exe, tmp_path):
     assert body.startswith("Method,Bodies,Dimension,Time(s)\n") and "BruteForce_Sequential" not in body
     # tiny inputs do not trip the reference's n/3 modulo (utils.h:141 is undefined for n < 3)
     assert _run(exe, tmp_path, "-N", "2", "-m", "a", "--seed", "1").returncode == 0
+
+
+def test_aggregate_results_has_the_analysis_columns(exe, tmp_path):
+    """tools/aggregate_results.py: per-run CSVs -> the reference's aggregated_results.csv schema
+    (nbody-sim-new/analysis/aggregated_results.csv:1)."""
+    for seed in ("1", "2"):
+        assert _run(exe, tmp_path, "-N", "200", "-d", "3", "-m", "a", "--seed", seed).returncode == 0
+        import time
+        time.sleep(1.1)  # run ids have one-second resolution
+    p = subprocess.run(["python3", os.path.join(ROOT, "tools", "aggregate_results.py"), "results"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = open(os.path.join(tmp_path, "results", "aggregated_results.csv")).read().strip().splitlines()
+    assert lines[0] == "Bodies,Method,Dimension,Average Runtime (s)"
+    assert any(l.startswith("200,BruteForce_Sequential,3,") for l in lines[1:])
