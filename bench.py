@@ -86,6 +86,10 @@ def main():
     import torch
     import torch.distributed as dist
     import nbody_amd as nbx
+    if not os.path.exists(nbx.LIB_PATH):  # checkout without build products: build in-tree first (rank 0 of a node only)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -34,6 +34,10 @@ def reference():
 def nbx():
     """The product package; on a GPU box a missing library is a hard failure, never a skip."""
     import nbody_amd
+    if not os.path.exists(nbody_amd.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "nbody_sim")):
+        # a checkout without build products: compile in-tree (hipcc cross-compiles gfx950 without a GPU)
+        import subprocess
+        subprocess.check_call(["make", "lib", "nbody_sim"], cwd=ROOT, stdout=subprocess.DEVNULL)
     nbody_amd.load_library()
     return nbody_amd
 
