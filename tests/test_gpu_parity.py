@@ -305,3 +305,30 @@ def test_fast_path_preconditions_fall_back_to_guarded_kernel(nbx, oracle):
         c.compute_accel()
         cr = oracle.round_inputs_to_f32(cur)
         assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(cr), oracle.force_magnitude_sums(cr), "after drift")
+
+
+def test_signed_and_extreme_coordinates(nbx, oracle):
+    """Bodies on both sides of the coordinate planes, at the origin, and spread over 12 decades of
+    separation: the candidate test works on |coordinate| and the fp32 path must neither overflow nor
+    lose the skip rule."""
+    n, dim = 4096, 3
+    rng = np.random.default_rng(5)
+    b = oracle.generate(8, n, dim)
+    b[:, :3] -= 5.0e6                                          # box centred on the origin: all sign combinations
+    b[:64, :3] = rng.normal(scale=30.0, size=(64, 3))          # a tight cluster straddling the planes
+    b[0, :3] = 0.0
+    b[1, :3] = (1e-4, -1e-4, 0.0)                              # 1.4e-4 from the origin: counted
+    b[2, :3] = (3e-6, 0.0, 0.0)                                # 3e-6 from the origin: r^2 = 9e-12, skipped
+    b[100, :3] = (-7.0e6, 7.0e6, -7.0e6)
+    b[101:104, -1] = (1.0, 1.0e-3, 9.9e7)
+    b = oracle.round_inputs_to_f32(b)
+    ref = oracle.brute_force_seq(b)
+    S = oracle.force_magnitude_sums(b)
+    for v, name in enumerate(nbx.variants()):
+        if not (name.startswith("fastpks_t8_w4_u4") or name.startswith("lds_t1_w8")):
+            continue
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.set_tuning(0, v)
+            c.compute_accel()
+            assert_force_parity(c.forces(oracle.G), ref, S, f"signed coordinates, {c.effective_tuning()[0]}")
