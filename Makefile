@@ -20,7 +20,7 @@ lib: $(LIB)
 OBJS := $(CSRC)/force_kernel_slp.o $(CSRC)/force_kernel_scalar.o $(CSRC)/force_launch.o \
         $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o
 # name of the force-kernel variant used when the caller does not pick one
-DEFAULT_VARIANT ?= fastpks_t8_w4_u4_scalar
+DEFAULT_VARIANT ?= fastpks_t8_w3_u4_scalar
 # exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
 DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8_scalar
 

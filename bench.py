@@ -86,10 +86,16 @@ def main():
     import torch
     import torch.distributed as dist
     import nbody_amd as nbx
-    if not os.path.exists(nbx.LIB_PATH):  # checkout without build products: build in-tree first (rank 0 of a node only)
+    if not os.path.exists(nbx.LIB_PATH):  # checkout without build products: local rank 0 builds in-tree, the others wait
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             import __graft_entry__
             __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(nbx.LIB_PATH) and os.path.exists(os.path.join(ROOT, "nbody_sim")):
+                    break
+                time.sleep(1.0)
+            time.sleep(2.0)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

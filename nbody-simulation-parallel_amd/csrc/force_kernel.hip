@@ -615,6 +615,7 @@ const KernelVariant kVariants[] = {
     {NBX_NAME("fastpks_t8_w4_u2"), 8, NBX_FASTS(4, 4, 2)},
     {NBX_NAME("fastpks_t8_w4_u4"), 8, NBX_FASTS(4, 4, 4)},
     {NBX_NAME("fastpks_t8_w3_u2"), 8, NBX_FASTS(4, 3, 2)},
+    {NBX_NAME("fastpks_t8_w3_u4"), 8, NBX_FASTS(4, 3, 4)},
     {NBX_NAME("fastpks_t4_w8_u4"), 4, NBX_FASTS(2, 8, 4)},
     {NBX_NAME("fastpks_t4_w4_u4"), 4, NBX_FASTS(2, 4, 4)},
     {NBX_NAME("fastpks_t16_w2_u2"), 16, NBX_FASTS(8, 2, 2)},
