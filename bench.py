@@ -176,14 +176,14 @@ def main():
         # are for the variant that just ran.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads (guide: x2
         # applies to 16-byte streaming loads), so the raw sum is reported.
         try:
-            prof = os.path.join(ROOT, "profiles", "r1b", "pmc_force_kernel.json")
+            prof = os.path.join(ROOT, "profiles", "r1c", "pmc_force_kernel.json")
             with open(prof) as f:
                 pmc = json.load(f)
-            if "accel_fast_pk_kernel<3, 4, 4, 4, 1>" in pmc["pmc_fetch"]["kernel"]["Kernel_Name"] and variant_name.startswith("fastpks_t8_w4_u4"):
+            if "accel_fast_pk_kernel<3, 4, 3, 4, 1>" in pmc["pmc_fetch"]["kernel"]["Kernel_Name"] and variant_name.startswith("fastpks_t8_w3_u4"):
                 fetch_kb = pmc["pmc_fetch"]["per_launch_mean"]["FETCH_SIZE"]
                 write_kb = pmc["pmc_write"]["per_launch_mean"]["WRITE_SIZE"]
                 result["roofline"]["traffic"] = (fetch_kb + write_kb) * 1024.0
-                result["roofline"]["traffic_source"] = "profiles/r1b/pmc_force_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; raw, per launch)"
+                result["roofline"]["traffic_source"] = "profiles/r1c/pmc_force_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; raw, per launch)"
         except Exception:
             pass
     if world > 1:
