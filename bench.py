@@ -68,6 +68,26 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=12.0):
                       f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}"}
 
 
+def accuracy_check(system, bodies, G, nrows=64):
+    """BASELINE metric, second half: max-abs / max-relative acceleration error of the device path against the
+    reference's sequential arithmetic (oracle rows in fp64 on the fp32-representable inputs), on sampled targets."""
+    import numpy as np
+    from oracle_lib import Oracle
+    o = Oracle()
+    n = bodies.shape[0]
+    system.be.ctx.upload(bodies)  # back to the initial state (the timed steps moved the bodies)
+    rounded = o.round_inputs_to_f32(bodies)
+    rows = np.unique(np.linspace(0, n - 1, nrows).astype(np.int64))
+    ref = o.force_rows_omp_2(rounded, rows)
+    system.compute_forces()
+    f = system.forces(G)[rows]
+    m = rounded[rows, -1][:, None]
+    da = (f - ref) / m
+    rel = np.sqrt((da ** 2).sum(1)) / np.sqrt(((ref / m) ** 2).sum(1))
+    return {"rows": int(rows.size), "max_abs_accel_err": float(np.abs(da).max()), "max_rel_accel_err": float(rel.max()),
+            "reference": "oracle rows of brute_force_omp_n_body_2 in fp64 on the fp32-rounded inputs (= sequential path up to fp64 re-association)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +210,7 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            result["accuracy"] = accuracy_check(system, bodies, G)   # on the initial positions: re-upload first
             result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)
         print(json.dumps(result), flush=True)
     be.close()
