@@ -18,7 +18,7 @@ all: lib oracle nbody_sim
 lib: $(LIB)
 
 OBJS := $(CSRC)/force_kernel_slp.o $(CSRC)/force_kernel_scalar.o $(CSRC)/force_launch.o \
-        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o
+        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o
 # name of the force-kernel variant used when the caller does not pick one
 DEFAULT_VARIANT ?= fastpks_t8_w3_u4_scalar
 # exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
@@ -38,11 +38,14 @@ $(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h Makefile
 $(CSRC)/state_kernels.o: $(CSRC)/state_kernels.hip $(CSRC)/nbx_internal.h
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
-$(CSRC)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.h include/nbody_hip.h
+$(CSRC)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/nbx_node.o: $(CSRC)/nbx_node.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -162,6 +162,32 @@ int nbx_default_variant(void);
  * the context's stream around each launch), and how many launches that covers.  Synchronises. */
 int nbx_ctx_kernel_time(nbx_ctx* ctx, float* mean_ms, int* launches);
 
+/* ---- single-process multi-GPU node ---------------------------------------------------------------
+ * The reference is single-process, single-device; this is new.  One context per rank
+ * (n_shards = n_ranks, shard = rank) on devices[rank] (NULL: 0..n_ranks-1; a device may appear more than
+ * once -- "virtual ranks", used to rehearse the sharded path on one GPU), driven by the calling thread.
+ * Per step every rank's freshly drifted fp32 position chunk is all-gathered on a second HIP stream while
+ * the rank's compute stream evaluates the forces from its own chunk; the pass over the other ranks'
+ * chunks waits on the exchange's event.  exchange: RCCL = ncclAllGather over one communicator per node
+ * (librccl is dlopen'ed on demand; needs distinct devices), PEER_COPY = every rank pushes its chunk into
+ * each peer's buffer with hipMemcpyPeerAsync, AUTO = RCCL when n_ranks > 1 distinct devices, else PEER_COPY.
+ * The one-process-per-GPU twin of this layer is nbody-simulation-parallel_amd/dist.py. */
+typedef struct nbx_node nbx_node;
+enum { NBX_EXCHANGE_AUTO = 0, NBX_EXCHANGE_PEER_COPY = 1, NBX_EXCHANGE_RCCL = 2 };
+int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, size_t n_total, int exchange);
+int nbx_node_destroy(nbx_node* node);
+int nbx_node_exchange_mode(const nbx_node* node, int* mode);
+int nbx_node_upload_bodies(nbx_node* node, const void* bodies, size_t body_stride_bytes);
+int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
+/* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
+int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
+/* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */
+int nbx_node_step(nbx_node* node, double G, double dt, int nsteps);
+int nbx_node_synchronize(nbx_node* node);
+int nbx_node_download_bodies(nbx_node* node, void* bodies, size_t body_stride_bytes);
+int nbx_node_energy(nbx_node* node, double G, double* kinetic, double* potential);
+int nbx_node_kernel_time(nbx_node* node, float* mean_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

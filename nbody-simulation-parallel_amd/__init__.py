@@ -9,7 +9,8 @@ through the root-level shim:  `import nbody_amd as nbx`  (or importlib with the 
   sharding.py, dist.py   one-process-per-GPU sharding over torch.distributed (RCCL)
 """
 from .capi import (  # noqa: F401
-    ABI, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE, Context, NbxError,
+    ABI, EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE,
+    Context, NbxError, Node,
     body_stride, brute_force_hip_n_body, device_count, leapfrog_hip_n_body, load_library, variants,
 )
 from . import generate, sharding  # noqa: E402,F401

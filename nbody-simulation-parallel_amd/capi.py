@@ -54,7 +54,19 @@ ABI = [
     ("nbx_variant_name", _c.c_char_p, [_i]),
     ("nbx_default_variant", _i, []),
     ("nbx_ctx_kernel_time", _i, [_vp, _pf, _pi]),
+    ("nbx_node_create", _i, [_c.POINTER(_vp), _i, _pi, _i, _sz, _i]),
+    ("nbx_node_destroy", _i, [_vp]),
+    ("nbx_node_exchange_mode", _i, [_vp, _pi]),
+    ("nbx_node_upload_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_node_set_tuning", _i, [_vp, _i, _i]),
+    ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
+    ("nbx_node_step", _i, [_vp, _d, _d, _i]),
+    ("nbx_node_synchronize", _i, [_vp]),
+    ("nbx_node_download_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_node_energy", _i, [_vp, _d, _pd, _pd]),
+    ("nbx_node_kernel_time", _i, [_vp, _pf, _pi]),
 ]
+EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1, 2
 
 
 class NbxError(RuntimeError):
@@ -242,4 +254,74 @@ class Context:
     def kernel_time(self) -> Tuple[float, int]:
         ms, cnt = ctypes.c_float(0.0), ctypes.c_int(0)
         self._ck(self.lib.nbx_ctx_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(cnt)), "nbx_ctx_kernel_time")
+        return ms.value, cnt.value
+
+
+class Node:
+    """Single-process multi-GPU node (nbx_node_* of include/nbody_hip.h): one rank per entry of `devices`
+    (a device may repeat: virtual ranks on one GPU)."""
+
+    def __init__(self, n_total: int, dim: int, devices, exchange: int = EXCHANGE_AUTO):
+        self.lib = load_library()
+        self.n_total, self.dim, self.devices = n_total, dim, list(devices)
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.nbx_node_create(ctypes.byref(h), len(self.devices), arr, dim, n_total, exchange), "nbx_node_create")
+        self.h = h
+        m = ctypes.c_int(0)
+        _check(self.lib, self.lib.nbx_node_exchange_mode(self.h, ctypes.byref(m)), "nbx_node_exchange_mode")
+        self.exchange = m.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbx_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc, where):
+        _check(self.lib, rc, where)
+
+    def upload(self, bodies: np.ndarray):
+        b, dim = _as_bodies(bodies)
+        if dim != self.dim or b.shape[0] != self.n_total:
+            raise ValueError("bodies shape does not match the node")
+        self._ck(self.lib.nbx_node_upload_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_node_upload_bodies")
+
+    def set_tuning(self, source_splits: int = 0, variant: int = -1):
+        self._ck(self.lib.nbx_node_set_tuning(self.h, source_splits, variant), "nbx_node_set_tuning")
+
+    def forces(self, G: float = REFERENCE_G) -> np.ndarray:
+        out = np.empty((self.n_total, self.dim), dtype=np.float64)
+        self._ck(self.lib.nbx_node_compute_forces(self.h, G, out.ctypes.data), "nbx_node_compute_forces")
+        return out
+
+    def step(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
+        self._ck(self.lib.nbx_node_step(self.h, G, dt, nsteps), "nbx_node_step")
+
+    def synchronize(self):
+        self._ck(self.lib.nbx_node_synchronize(self.h), "nbx_node_synchronize")
+
+    def download(self, bodies: np.ndarray):
+        b, dim = _as_bodies(bodies, writable=True)
+        self._ck(self.lib.nbx_node_download_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_node_download_bodies")
+
+    def energy(self, G: float = REFERENCE_G) -> Tuple[float, float]:
+        ke, pe = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._ck(self.lib.nbx_node_energy(self.h, G, ctypes.byref(ke), ctypes.byref(pe)), "nbx_node_energy")
+        return ke.value, pe.value
+
+    def kernel_time(self) -> Tuple[float, int]:
+        ms, cnt = ctypes.c_float(0.0), ctypes.c_int(0)
+        self._ck(self.lib.nbx_node_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(cnt)), "nbx_node_kernel_time")
         return ms.value, cnt.value

@@ -3,6 +3,7 @@
 // entry point that needs the device fails loudly when HIP does.
 #include "../../include/nbody_hip.h"
 #include "nbx_internal.h"
+#include "nbx_ctx.h"
 
 #include <climits>
 #include <cstdio>
@@ -17,7 +18,9 @@ using namespace nbx;
 namespace {
 
 thread_local std::string g_detail;
+}  // namespace
 
+namespace nbx {
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
     std::snprintf(buf, sizeof buf, "%s failed: %s (%s) at %s:%d", what, hipGetErrorString(e), hipGetErrorName(e), file, line);
@@ -30,6 +33,9 @@ int fail(int code, const char* msg) {
     g_detail = msg;
     return code;
 }
+}  // namespace nbx
+
+namespace {
 
 #define HIP_TRY(expr)                                                     \
     do {                                                                  \
@@ -44,50 +50,6 @@ constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from
 
 }  // namespace
 
-struct nbx_ctx {
-    int device = 0, dim = 3, n_shards = 1, shard = 0;
-    size_t n_total = 0, shard_len = 0, count = 0;  // count = real bodies in this shard
-    unsigned pad = 0;
-    int splits = 1, variant = 0;
-    bool splits_user = false;
-    bool uploaded = false, have_accel = false;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    // exchange buffers (own or caller's)
-    float* pos_all = nullptr;
-    float* mass_all = nullptr;
-    bool own_gather = true;
-    // own shard
-    double *x64 = nullptr, *v64 = nullptr, *m64 = nullptr;
-    float* acc = nullptr;
-    int acc_splits_alloc = 0;
-    // fast-path workspace (close-set pipeline) and its preconditions
-    unsigned* cand_list = nullptr;
-    float* cand_pos = nullptr;
-    unsigned* bad_list = nullptr;
-    unsigned char* bad_flag = nullptr;
-    unsigned* counters = nullptr;
-    float* close_acc = nullptr;
-    int close_splits_alloc = 0;
-    float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
-    // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
-    hipGraphExec_t step_exec = nullptr;
-    double graph_G = 0.0, graph_dt = 0.0;
-    int graph_variant = -1, graph_splits = 0;
-    hipStream_t graph_stream = nullptr;
-    bool capturing = false;
-    bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
-    int close_list_valid = 0;   // the device list matches the positions in pos_all
-    bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
-    int variant_req = -1;       // what the caller asked for (-1: library default)
-    // boundary staging
-    double* stage = nullptr;
-    size_t stage_bytes = 0;
-    // kernel timing
-    std::vector<hipEvent_t> ev0, ev1;
-    int ev_used = 0;
-    int launches_since_query = 0;
-    int num_cus = 256;
-};
 
 namespace {
 

@@ -1,0 +1,67 @@
+// nbx_ctx.h -- private definition of the opaque context of include/nbody_hip.h, shared by nbx_api.hip and
+// nbx_node.hip (not installed).
+#ifndef NBX_CTX_H
+#define NBX_CTX_H
+
+#include <vector>
+
+#include "nbx_internal.h"
+
+struct nbx_ctx {
+    int device = 0, dim = 3, n_shards = 1, shard = 0;
+    size_t n_total = 0, shard_len = 0, count = 0;  // count = real bodies in this shard
+    unsigned pad = 0;
+    int splits = 1, variant = 0;
+    bool splits_user = false;
+    bool uploaded = false, have_accel = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // exchange buffers (own or caller's)
+    float* pos_all = nullptr;
+    float* mass_all = nullptr;
+    bool own_gather = true;
+    // own shard
+    double *x64 = nullptr, *v64 = nullptr, *m64 = nullptr;
+    float* acc = nullptr;
+    int acc_splits_alloc = 0;
+    // fast-path workspace (close-set pipeline) and its preconditions
+    unsigned* cand_list = nullptr;
+    float* cand_pos = nullptr;
+    unsigned* bad_list = nullptr;
+    unsigned char* bad_flag = nullptr;
+    unsigned* counters = nullptr;
+    float* close_acc = nullptr;
+    int close_splits_alloc = 0;
+    float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
+    // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
+    hipGraphExec_t step_exec = nullptr;
+    double graph_G = 0.0, graph_dt = 0.0;
+    int graph_variant = -1, graph_splits = 0;
+    hipStream_t graph_stream = nullptr;
+    bool capturing = false;
+    bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
+    int close_list_valid = 0;   // the device list matches the positions in pos_all
+    bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
+    int variant_req = -1;       // what the caller asked for (-1: library default)
+    // boundary staging
+    double* stage = nullptr;
+    size_t stage_bytes = 0;
+    // kernel timing
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_used = 0;
+    int launches_since_query = 0;
+    int num_cus = 256;
+};
+
+namespace nbx {
+// error plumbing of the C ABI (nbx_api.hip): record the detail text, return the status code
+int fail_hip(hipError_t e, const char* what, const char* file, int line);
+int fail(int code, const char* msg);
+}  // namespace nbx
+
+#define NBX_HIP_TRY(expr)                                                           \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) return nbx::fail_hip(e_, #expr, __FILE__, __LINE__);  \
+    } while (0)
+
+#endif

@@ -1,0 +1,366 @@
+// nbx_node.hip -- single-process multi-GPU driver of the C ABI (nbx_node_*): one context per rank, one
+// host thread issuing asynchronous work round-robin over the ranks' streams.
+//
+// Per step:  every rank's comm stream all-gathers the freshly drifted fp32 position chunks
+// (RCCL ncclAllGather in one group call, in place in each rank's pos_all; or, for ranks that share a
+// device / when RCCL is unavailable, direct peer copies of the own chunk into every peer's buffer) while
+// its compute stream runs the LOCAL source pass; the REMOTE pass waits on the exchange's event; the fused
+// kick+drift rewrites the own chunk and records the event the next exchange waits on.
+//
+// This is the C++-side twin of nbody-simulation-parallel_amd/dist.py (one process per GPU over
+// torch.distributed); both drive the same kernels through the same context calls.  librccl is opened with
+// dlopen only when the RCCL exchange is requested, so the single-GPU path has no dependency on it.
+#include "../../include/nbody_hip.h"
+#include "nbx_ctx.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace nbx;
+
+namespace {
+
+// the few RCCL entry points used (rccl/rccl.h: ncclCommInitAll :236, ncclCommDestroy :260, ncclAllGather :678,
+// ncclGroupStart/End :923; ncclFloat32 = 7, ncclSuccess = 0)
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+    }
+};
+constexpr int kNcclFloat32 = 7;
+
+struct Rank {
+    nbx_ctx* ctx = nullptr;
+    int device = 0;
+    hipStream_t comm = nullptr;
+    hipEvent_t ready = nullptr;      // own chunk final and own REMOTE pass done (recorded on the compute stream)
+    hipEvent_t exchanged = nullptr;  // this rank's part of the exchange done (recorded on the comm stream)
+    void* nccl = nullptr;
+    float* pos_all = nullptr;
+    size_t chunk_floats = 0;
+};
+
+}  // namespace
+
+struct nbx_node {
+    int n_ranks = 0, dim = 3, exchange = NBX_EXCHANGE_PEER_COPY;
+    size_t n_total = 0, shard_len = 0;
+    std::vector<Rank> ranks;
+    Rccl rccl;
+    bool uploaded = false;
+};
+
+namespace {
+
+int nccl_fail(nbx_node* nd, int rc, const char* what) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s failed: %s", what, nd->rccl.GetErrorString ? nd->rccl.GetErrorString(rc) : "rccl error");
+    return fail(NBX_ERR_HIP, buf);
+}
+
+// Launch the position exchange on the comm streams.  Every rank's comm stream first waits for the events
+// that make its reads and writes safe: its own `ready` (own chunk final), and -- for peer copies, which
+// write into other ranks' buffers -- every destination rank's `ready` (that rank no longer reads the old
+// copy of this chunk).  With RCCL the receiver's own comm stream orders the writes behind its `ready`.
+int start_exchange(nbx_node* nd) {
+    const int R = nd->n_ranks;
+    if (R == 1) return NBX_OK;
+    for (int r = 0; r < R; ++r) {
+        Rank& k = nd->ranks[r];
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        NBX_HIP_TRY(hipStreamWaitEvent(k.comm, k.ready, 0));
+        if (nd->exchange == NBX_EXCHANGE_PEER_COPY)
+            for (int q = 0; q < R; ++q)
+                if (q != r) NBX_HIP_TRY(hipStreamWaitEvent(k.comm, nd->ranks[q].ready, 0));
+    }
+    if (nd->exchange == NBX_EXCHANGE_RCCL) {
+        int rc = nd->rccl.GroupStart();
+        if (rc) return nccl_fail(nd, rc, "ncclGroupStart");
+        for (int r = 0; r < R; ++r) {
+            Rank& k = nd->ranks[r];
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            rc = nd->rccl.AllGather(k.pos_all + (size_t)r * k.chunk_floats, k.pos_all, k.chunk_floats, kNcclFloat32, k.nccl, k.comm);
+            if (rc) { (void)nd->rccl.GroupEnd(); return nccl_fail(nd, rc, "ncclAllGather"); }
+        }
+        rc = nd->rccl.GroupEnd();
+        if (rc) return nccl_fail(nd, rc, "ncclGroupEnd");
+    } else {
+        for (int r = 0; r < R; ++r) {
+            Rank& k = nd->ranks[r];
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            const size_t off = (size_t)r * k.chunk_floats, bytes = k.chunk_floats * sizeof(float);
+            for (int q = 0; q < R; ++q) {
+                if (q == r) continue;
+                Rank& dst = nd->ranks[q];
+                NBX_HIP_TRY(hipMemcpyPeerAsync(dst.pos_all + off, dst.device, k.pos_all + off, k.device, bytes, k.comm));
+            }
+        }
+    }
+    for (int r = 0; r < R; ++r) {
+        Rank& k = nd->ranks[r];
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        NBX_HIP_TRY(hipEventRecord(k.exchanged, k.comm));
+    }
+    return NBX_OK;
+}
+
+// Make every rank's compute stream wait until its exchange buffer is complete.
+int finish_exchange(nbx_node* nd) {
+    const int R = nd->n_ranks;
+    if (R == 1) return NBX_OK;
+    for (int r = 0; r < R; ++r) {
+        Rank& k = nd->ranks[r];
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        if (nd->exchange == NBX_EXCHANGE_RCCL) {
+            NBX_HIP_TRY(hipStreamWaitEvent(k.ctx->stream, k.exchanged, 0));
+        } else {
+            for (int q = 0; q < R; ++q)  // every peer pushed its chunk into this rank's buffer
+                if (q != r) NBX_HIP_TRY(hipStreamWaitEvent(k.ctx->stream, nd->ranks[q].exchanged, 0));
+        }
+    }
+    return NBX_OK;
+}
+
+int mark_ready(nbx_node* nd) {
+    for (Rank& k : nd->ranks) {
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        NBX_HIP_TRY(hipEventRecord(k.ready, k.ctx->stream));
+    }
+    return NBX_OK;
+}
+
+// One force evaluation on every rank: exchange || LOCAL pass, then REMOTE pass.
+int evaluate(nbx_node* nd) {
+    int rc = start_exchange(nd);
+    if (rc) return rc;
+    for (Rank& k : nd->ranks) {
+        rc = nbx_ctx_compute_accel(k.ctx, nd->n_ranks == 1 ? NBX_SRC_ALL : NBX_SRC_LOCAL);
+        if (rc) return rc;
+    }
+    if (nd->n_ranks == 1) return NBX_OK;
+    rc = finish_exchange(nd);
+    if (rc) return rc;
+    for (Rank& k : nd->ranks) {
+        rc = nbx_ctx_compute_accel(k.ctx, NBX_SRC_REMOTE);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, size_t n_total, int exchange) {
+    if (!out) return fail(NBX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_ranks < 1 || n_ranks > 64) return fail(NBX_ERR_INVALID, "n_ranks must be in [1,64]");
+    if (exchange < NBX_EXCHANGE_AUTO || exchange > NBX_EXCHANGE_RCCL) return fail(NBX_ERR_INVALID, "bad exchange mode");
+    nbx_node* nd = new (std::nothrow) nbx_node();
+    if (!nd) return fail(NBX_ERR_ALLOC, "host allocation failed");
+    nd->n_ranks = n_ranks; nd->dim = dim; nd->n_total = n_total;
+    nd->ranks.resize((size_t)n_ranks);
+    bool distinct = true;
+    for (int r = 0; r < n_ranks; ++r) {
+        nd->ranks[r].device = devices ? devices[r] : r;
+        for (int q = 0; q < r; ++q) distinct = distinct && nd->ranks[q].device != nd->ranks[r].device;
+    }
+    if (exchange == NBX_EXCHANGE_AUTO) exchange = (n_ranks > 1 && distinct && nd->rccl.load()) ? NBX_EXCHANGE_RCCL : NBX_EXCHANGE_PEER_COPY;
+    if (exchange == NBX_EXCHANGE_RCCL && n_ranks > 1 && !distinct) { delete nd; return fail(NBX_ERR_INVALID, "RCCL needs one distinct device per rank"); }
+    if (exchange == NBX_EXCHANGE_RCCL && !nd->rccl.load()) { delete nd; return fail(NBX_ERR_HIP, "librccl.so could not be loaded"); }
+    nd->exchange = exchange;
+#define NODE_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) { int r_ = fail_hip(e_, #expr, __FILE__, __LINE__); nbx_node_destroy(nd); return r_; } \
+    } while (0)
+    for (int r = 0; r < n_ranks; ++r) {
+        Rank& k = nd->ranks[r];
+        int rc = nbx_ctx_create(&k.ctx, k.device, dim, n_total, n_ranks, r);
+        if (rc) { nbx_node_destroy(nd); return rc; }
+        NODE_TRY(hipSetDevice(k.device));
+        NODE_TRY(hipStreamCreateWithFlags(&k.comm, hipStreamNonBlocking));
+        NODE_TRY(hipEventCreateWithFlags(&k.ready, hipEventDisableTiming));
+        NODE_TRY(hipEventCreateWithFlags(&k.exchanged, hipEventDisableTiming));
+        for (int q = 0; q < n_ranks; ++q) {  // direct xGMI copies where the devices allow it; ignored otherwise
+            const int other = devices ? devices[q] : q;
+            if (other != k.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, k.device, other) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(other, 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+#undef NODE_TRY
+    nd->shard_len = nd->ranks[0].ctx->shard_len;
+    if (exchange == NBX_EXCHANGE_RCCL) {
+        std::vector<void*> comms((size_t)n_ranks, nullptr);
+        std::vector<int> devs((size_t)n_ranks);
+        for (int r = 0; r < n_ranks; ++r) devs[r] = nd->ranks[r].device;
+        const int rc = nd->rccl.CommInitAll(comms.data(), n_ranks, devs.data());
+        if (rc) { int e = nccl_fail(nd, rc, "ncclCommInitAll"); nbx_node_destroy(nd); return e; }
+        for (int r = 0; r < n_ranks; ++r) nd->ranks[r].nccl = comms[r];
+    }
+    *out = nd;
+    return NBX_OK;
+}
+
+int nbx_node_destroy(nbx_node* nd) {
+    if (!nd) return NBX_OK;
+    for (Rank& k : nd->ranks) {
+        (void)hipSetDevice(k.device);
+        if (k.ctx) (void)nbx_ctx_synchronize(k.ctx);
+        if (k.comm) (void)hipStreamSynchronize(k.comm);
+    }
+    for (Rank& k : nd->ranks) {
+        (void)hipSetDevice(k.device);
+        if (k.nccl && nd->rccl.CommDestroy) (void)nd->rccl.CommDestroy(k.nccl);
+        if (k.ready) (void)hipEventDestroy(k.ready);
+        if (k.exchanged) (void)hipEventDestroy(k.exchanged);
+        if (k.comm) (void)hipStreamDestroy(k.comm);
+        if (k.ctx) (void)nbx_ctx_destroy(k.ctx);
+    }
+    delete nd;
+    return NBX_OK;
+}
+
+int nbx_node_exchange_mode(const nbx_node* nd, int* mode) {
+    if (!nd || !mode) return fail(NBX_ERR_INVALID, "null argument");
+    *mode = nd->exchange;
+    return NBX_OK;
+}
+
+int nbx_node_upload_bodies(nbx_node* nd, const void* bodies, size_t stride_bytes) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        int rc = nbx_ctx_upload_bodies(k.ctx, bodies, stride_bytes);  // fills every chunk of this rank's source copy
+        if (rc) return rc;
+        k.pos_all = k.ctx->pos_all;
+        k.chunk_floats = (size_t)nd->dim * k.ctx->pad;
+    }
+    nd->uploaded = true;
+    return mark_ready(nd);
+}
+
+int nbx_node_set_tuning(nbx_node* nd, int source_splits, int variant) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        int rc = nbx_ctx_set_tuning(k.ctx, source_splits, variant);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_compute_forces(nbx_node* nd, double G, double* forces_out) {
+    if (!nd || (!forces_out && nd->n_total)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    int rc = evaluate(nd);
+    if (rc) return rc;
+    rc = mark_ready(nd);
+    if (rc) return rc;
+    for (int r = 0; r < nd->n_ranks; ++r) {
+        Rank& k = nd->ranks[r];
+        if (k.ctx->count == 0) continue;
+        rc = nbx_ctx_get_forces(k.ctx, G, forces_out + (size_t)r * nd->shard_len * nd->dim);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_step(nbx_node* nd, double G, double dt, int nsteps) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps < 0");
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = evaluate(nd);
+        if (rc) return rc;
+        for (Rank& k : nd->ranks) {
+            rc = nbx_ctx_kick_drift(k.ctx, G, dt);
+            if (rc) return rc;
+        }
+        rc = mark_ready(nd);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_synchronize(nbx_node* nd) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        NBX_HIP_TRY(hipStreamSynchronize(k.comm));
+        int rc = nbx_ctx_synchronize(k.ctx);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_download_bodies(nbx_node* nd, void* bodies, size_t stride_bytes) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        if (k.ctx->count == 0) continue;
+        int rc = nbx_ctx_download_bodies(k.ctx, bodies, stride_bytes);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_energy(nbx_node* nd, double G, double* kinetic, double* potential) {
+    if (!nd || !kinetic || !potential) return fail(NBX_ERR_INVALID, "null argument");
+    if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    int rc = start_exchange(nd);  // every rank's source copy must hold the current positions
+    if (!rc) rc = finish_exchange(nd);
+    if (rc) return rc;
+    double ke = 0.0, pe = 0.0;
+    for (Rank& k : nd->ranks) {
+        double a = 0.0, b = 0.0;
+        rc = nbx_ctx_energy(k.ctx, G, &a, &b);
+        if (rc) return rc;
+        ke += a;
+        pe += b;
+    }
+    *kinetic = ke;
+    *potential = pe;
+    return mark_ready(nd);
+}
+
+int nbx_node_kernel_time(nbx_node* nd, float* mean_ms, int* launches) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    double sum = 0.0;
+    int cnt = 0;
+    for (Rank& k : nd->ranks) {
+        float ms = 0.f;
+        int c = 0;
+        int rc = nbx_ctx_kernel_time(k.ctx, &ms, &c);
+        if (rc) return rc;
+        sum += (double)ms * c;
+        cnt += c;
+    }
+    if (mean_ms) *mean_ms = cnt ? (float)(sum / cnt) : 0.f;
+    if (launches) *launches = cnt;
+    return NBX_OK;
+}
+
+}  // extern "C"

@@ -34,6 +34,7 @@ struct Options {
     double dt = 1.0;
     std::string init = "uniform";   // uniform | plummer
     std::string dump;               // prefix: write bodies and each method's forces as raw doubles
+    std::vector<int> devices;       // --gpus / --devices: shard the HIP rows over these GPUs (one process)
 };
 
 template <typename T>
@@ -181,6 +182,8 @@ void usage(const char* argv0) {
               << "      --init <uniform|plummer>  Initial condition (default: uniform)" << std::endl
               << "      --steps <k>     Also run k kick-drift steps on the device" << std::endl
               << "      --dt <t>        Time step for --steps (default: 1)" << std::endl
+              << "      --gpus <g>      Shard the HIP rows over GPUs 0..g-1 of this node (one process, RCCL all-gather per step)" << std::endl
+              << "      --devices <list> Same with an explicit device list, e.g. 0,0,0 = three virtual ranks on GPU 0" << std::endl
               << "      --dump <prefix> Write bodies and every method's forces as raw doubles (<prefix>_<Method>.f64)" << std::endl
               << "  -h, --help          Display this help message" << std::endl;
 }
@@ -221,6 +224,24 @@ int main(int argc, char* argv[]) {
             opt.steps = std::stoi(argv[++i]);
         } else if (arg == "--dt" && has_value) {
             opt.dt = std::stod(argv[++i]);
+        } else if (arg == "--gpus" && has_value) {
+            const int g = std::stoi(argv[++i]);
+            if (g < 1 || g > 64) {
+                std::cerr << "Error: --gpus must be in [1,64]" << std::endl;
+                return 1;
+            }
+            opt.devices.clear();
+            for (int d = 0; d < g; ++d) opt.devices.push_back(d);
+        } else if (arg == "--devices" && has_value) {   // e.g. --devices 0,0,0 = three virtual ranks on GPU 0
+            opt.devices.clear();
+            std::string list = argv[++i];
+            std::size_t pos = 0;
+            while (pos <= list.size()) {
+                const std::size_t comma = list.find(',', pos);
+                opt.devices.push_back(std::stoi(list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos)));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
         } else if (arg == "--dump" && has_value) {
             opt.dump = argv[++i];
         } else if (arg == "--init" && has_value) {
@@ -235,6 +256,7 @@ int main(int argc, char* argv[]) {
         }
     }
 
+    set_hip_devices(opt.devices);
     const std::string run_id = get_run_id();
     try {
         if (opt.dimension == 2) {

@@ -4,12 +4,20 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "nbody_hip.h"
 
 namespace {
 thread_local HipRunInfo g_info;
 int g_device = -1;
+std::vector<int> g_devices;  // more than one entry: sharded over a node
+
+// RAII over the node handle so an exception cannot leak device memory
+struct NodeHandle {
+    nbx_node* h = nullptr;
+    ~NodeHandle() { nbx_node_destroy(h); }
+};
 
 int device_ordinal() {
     if (g_device >= 0) return g_device;
@@ -27,11 +35,25 @@ int device_ordinal() {
 
 const HipRunInfo& last_hip_run_info() { return g_info; }
 void set_hip_device(int device) { g_device = device; }
+void set_hip_devices(const std::vector<int>& devices) { g_devices = devices; }
 
 template <int D>
 std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies) {
     std::vector<Vector<D>> forces(bodies.size());
     g_info = HipRunInfo{};
+    if (g_devices.size() > 1) {
+        NodeHandle node;
+        int rc = nbx_node_create(&node.h, (int)g_devices.size(), g_devices.data(), D, bodies.size(), NBX_EXCHANGE_AUTO);
+        if (!rc) rc = nbx_node_upload_bodies(node.h, bodies.data(), sizeof(Body<D>));
+        if (!rc) rc = nbx_node_compute_forces(node.h, NBX_REFERENCE_G, reinterpret_cast<double*>(forces.data()));
+        int launches = 0;
+        float mean = 0.f;
+        if (!rc) rc = nbx_node_kernel_time(node.h, &mean, &launches);
+        if (rc != NBX_OK) raise("brute_force_hip_n_body (node)", rc);
+        g_info.kernel_ms = mean * (float)launches / (float)g_devices.size();  // per-rank share: ranks run concurrently
+        g_info.device = g_devices[0];
+        return forces;
+    }
     g_info.device = device_ordinal();
     const int rc = nbx_brute_force_forces(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G,
                                           g_info.device, reinterpret_cast<double*>(forces.data()), &g_info.kernel_ms);
@@ -42,6 +64,21 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 template <int D>
 void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps) {
     g_info = HipRunInfo{};
+    if (g_devices.size() > 1) {
+        NodeHandle node;
+        int rc = nbx_node_create(&node.h, (int)g_devices.size(), g_devices.data(), D, bodies.size(), NBX_EXCHANGE_AUTO);
+        if (!rc) rc = nbx_node_upload_bodies(node.h, bodies.data(), sizeof(Body<D>));
+        if (!rc) rc = nbx_node_step(node.h, NBX_REFERENCE_G, dt, nsteps);
+        if (!rc) rc = nbx_node_synchronize(node.h);
+        if (!rc) rc = nbx_node_download_bodies(node.h, bodies.data(), sizeof(Body<D>));
+        int launches = 0;
+        float mean = 0.f;
+        if (!rc) rc = nbx_node_kernel_time(node.h, &mean, &launches);
+        if (rc != NBX_OK) raise("leapfrog_hip_n_body (node)", rc);
+        g_info.kernel_ms = mean * (float)launches / (float)g_devices.size();
+        g_info.device = g_devices[0];
+        return;
+    }
     g_info.device = device_ordinal();
     const int rc = nbx_leapfrog(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G, dt, nsteps,
                                 g_info.device, &g_info.kernel_ms);

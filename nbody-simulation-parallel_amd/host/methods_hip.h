@@ -35,4 +35,9 @@ const HipRunInfo& last_hip_run_info();
 // Device ordinal used by the two entry points above (default 0; NBODY_HIP_DEVICE overrides).
 void set_hip_device(int device);
 
+// Shard the bodies over several GPUs of the node inside this process (nbx_node_* of nbody_hip.h: one
+// context per entry, RCCL all-gather of positions per step, or peer copies when entries share a device).
+// An empty list or a single entry selects the single-GPU path.
+void set_hip_devices(const std::vector<int>& devices);
+
 #endif  // NBODY_AMD_METHODS_HIP_H

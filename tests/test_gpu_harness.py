@@ -50,3 +50,17 @@ def test_hip_only_large_n_and_leapfrog(tmp_path, oracle):
     f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
     br = oracle.round_inputs_to_f32(bodies)
     assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "harness sampled rows")
+
+
+def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
+    """`--devices 0,0,0`: the C++ wrappers shard over three virtual ranks of GPU 0 (nbx_node_*)."""
+    n = 20000
+    p = _run(tmp_path, "-N", str(n), "-m", "g", "--seed", "6", "--steps", "2", "--dt", "3", "--devices", "0,0,0", "--dump", "d")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
+    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
+    br = oracle.round_inputs_to_f32(bodies)
+    rows = np.arange(0, n, 97)
+    assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "sharded harness rows")
+    state = np.fromfile(os.path.join(tmp_path, "d_Leapfrog_HIP.f64")).reshape(n, 7)
+    assert np.allclose(state[:, :3], bodies[:, :3] + bodies[:, 3:6] * 6.0, rtol=1e-12, atol=0)
