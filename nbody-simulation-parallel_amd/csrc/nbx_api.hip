@@ -25,6 +25,7 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
     std::snprintf(buf, sizeof buf, "%s failed: %s (%s) at %s:%d", what, hipGetErrorString(e), hipGetErrorName(e), file, line);
     g_detail = buf;
+    (void)hipGetLastError();  // reset the runtime's sticky last-error so a later launch check does not see this one
     return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? NBX_ERR_NO_DEVICE
            : (e == hipErrorOutOfMemory)                           ? NBX_ERR_ALLOC
                                                                   : NBX_ERR_HIP;
@@ -125,6 +126,7 @@ int ensure_acc(nbx_ctx* c) {
 }
 
 int set_device(const nbx_ctx* c) {
+    (void)hipGetLastError();  // launches are checked with hipGetLastError(): start from a clean slate
     HIP_TRY(hipSetDevice(c->device));
     return NBX_OK;
 }

@@ -230,18 +230,21 @@ int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, si
 int nbx_node_destroy(nbx_node* nd) {
     if (!nd) return NBX_OK;
     for (Rank& k : nd->ranks) {
+        if (!k.ctx) continue;  // never created (e.g. bad device ordinal): nothing on that device
         (void)hipSetDevice(k.device);
-        if (k.ctx) (void)nbx_ctx_synchronize(k.ctx);
+        (void)nbx_ctx_synchronize(k.ctx);
         if (k.comm) (void)hipStreamSynchronize(k.comm);
     }
     for (Rank& k : nd->ranks) {
+        if (!k.ctx) continue;
         (void)hipSetDevice(k.device);
         if (k.nccl && nd->rccl.CommDestroy) (void)nd->rccl.CommDestroy(k.nccl);
         if (k.ready) (void)hipEventDestroy(k.ready);
         if (k.exchanged) (void)hipEventDestroy(k.exchanged);
         if (k.comm) (void)hipStreamDestroy(k.comm);
-        if (k.ctx) (void)nbx_ctx_destroy(k.ctx);
+        (void)nbx_ctx_destroy(k.ctx);
     }
+    (void)hipGetLastError();
     delete nd;
     return NBX_OK;
 }
