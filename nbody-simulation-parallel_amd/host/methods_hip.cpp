@@ -85,6 +85,47 @@ void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps) {
     if (rc != NBX_OK) raise("leapfrog_hip_n_body", rc);
 }
 
+template <int D>
+HipSimulation<D>::HipSimulation(const std::vector<Body<D>>& bodies, double G) : G_(G) {
+    std::vector<int> devs = g_devices.empty() ? std::vector<int>{device_ordinal()} : g_devices;
+    ranks_ = (int)devs.size();
+    int rc = nbx_node_create(&node_, ranks_, devs.data(), D, bodies.size(), NBX_EXCHANGE_AUTO);
+    if (!rc) rc = nbx_node_upload_bodies(node_, bodies.data(), sizeof(Body<D>));
+    if (rc != NBX_OK) {
+        nbx_node_destroy(node_);
+        node_ = nullptr;
+        raise("HipSimulation", rc);
+    }
+}
+template <int D>
+HipSimulation<D>::~HipSimulation() { nbx_node_destroy(node_); }
+template <int D>
+void HipSimulation<D>::step(double dt, int nsteps) {
+    const int rc = nbx_node_step(node_, G_, dt, nsteps);
+    if (rc != NBX_OK) raise("HipSimulation::step", rc);
+}
+template <int D>
+void HipSimulation<D>::energy(double& kinetic, double& potential) {
+    const int rc = nbx_node_energy(node_, G_, &kinetic, &potential);
+    if (rc != NBX_OK) raise("HipSimulation::energy", rc);
+}
+template <int D>
+void HipSimulation<D>::download(std::vector<Body<D>>& bodies) {
+    int rc = nbx_node_synchronize(node_);
+    if (!rc) rc = nbx_node_download_bodies(node_, bodies.data(), sizeof(Body<D>));
+    if (rc != NBX_OK) raise("HipSimulation::download", rc);
+}
+template <int D>
+double HipSimulation<D>::force_kernel_seconds() {
+    float mean = 0.f;
+    int launches = 0;
+    const int rc = nbx_node_kernel_time(node_, &mean, &launches);
+    if (rc != NBX_OK) raise("HipSimulation::force_kernel_seconds", rc);
+    return (double)mean * launches / ranks_ * 1e-3;
+}
+template class HipSimulation<2>;
+template class HipSimulation<3>;
+
 // explicit instantiations, like nbody-sim-new/methods.cpp:452-499 does for the CPU solvers
 template std::vector<Vector<2>> brute_force_hip_n_body<2>(const std::vector<Body<2>>&);
 template std::vector<Vector<3>> brute_force_hip_n_body<3>(const std::vector<Body<3>>&);

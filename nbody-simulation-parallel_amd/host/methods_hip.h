@@ -25,6 +25,27 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 template <int D>
 void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps);
 
+// Device-resident simulation for callers that want to look at the system between steps (energy-drift
+// logging, BASELINE config 5): bodies are uploaded once, stepped on the device(s), read back on demand.
+// Uses the devices of set_hip_devices() (one GPU by default).  Every method throws std::runtime_error on
+// a device failure.
+template <int D>
+class HipSimulation {
+public:
+    HipSimulation(const std::vector<Body<D>>& bodies, double G);
+    ~HipSimulation();
+    HipSimulation(const HipSimulation&) = delete;
+    HipSimulation& operator=(const HipSimulation&) = delete;
+    void step(double dt, int nsteps);            // asynchronous
+    void energy(double& kinetic, double& potential);  // of the whole system, under the reference law's potential
+    void download(std::vector<Body<D>>& bodies);
+    double force_kernel_seconds();               // per-rank force-kernel time since the last call
+private:
+    struct nbx_node* node_ = nullptr;
+    double G_;
+    int ranks_ = 1;
+};
+
 // Timing of the most recent call on this thread, for pair-interactions/s and roofline reporting.
 struct HipRunInfo {
     float kernel_ms = 0.0f;   // force-kernel time only (hipEvent), summed over the call's launches

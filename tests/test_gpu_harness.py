@@ -64,3 +64,15 @@ def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
     assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "sharded harness rows")
     state = np.fromfile(os.path.join(tmp_path, "d_Leapfrog_HIP.f64")).reshape(n, 7)
     assert np.allclose(state[:, :3], bodies[:, :3] + bodies[:, 3:6] * 6.0, rtol=1e-12, atol=0)
+
+
+def test_plummer_energy_logging(tmp_path):
+    """BASELINE config 5 through the C++ harness, scaled down: Plummer sphere, device-resident steps over two
+    virtual ranks, energy logged every 20 steps."""
+    import re
+    p = _run(tmp_path, "-N", "8192", "-m", "g", "--init", "plummer", "--seed", "3", "--steps", "100", "--dt", "1",
+             "--G", "1e3", "--energy-every", "20", "--devices", "0,0")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    drifts = [float(x) for x in re.findall(r"\|dE/E0\| = ([0-9.eE+-]+)", p.stdout)]
+    assert len(drifts) == 5 and max(drifts) < 0.1, p.stdout
+    assert re.search(r"step 0  E = ", p.stdout)
