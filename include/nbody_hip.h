@@ -56,6 +56,10 @@ const char* nbx_strerror(int status);
 /* Text of the last HIP failure seen by the calling thread ("" if none). */
 const char* nbx_last_error_detail(void);
 int nbx_device_count(int* count);
+/* One-time start-up of `device` (HIP runtime, code-object load, first launches; ~0.15 s) so that a harness
+ * that times whole calls, like the reference's safely_execute (utils.h:87-104), does not charge it to the
+ * first solver call -- the way OpenMP's thread pool is already up when the reference times its CPU rows. */
+int nbx_warmup(int device);
 
 /* ---- one-shot entry points (host memory in, host memory out) --------------------------------- */
 

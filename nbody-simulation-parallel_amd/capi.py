@@ -32,6 +32,7 @@ ABI = [
     ("nbx_strerror", _c.c_char_p, [_i]),
     ("nbx_last_error_detail", _c.c_char_p, []),
     ("nbx_device_count", _i, [_pi]),
+    ("nbx_warmup", _i, [_i]),
     ("nbx_brute_force_forces", _i, [_vp, _sz, _i, _sz, _d, _i, _vp, _pf]),
     ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
     ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),

@@ -165,6 +165,19 @@ int nbx_device_count(int* count) {
     return n > 0 ? NBX_OK : fail(NBX_ERR_NO_DEVICE, "hipGetDeviceCount returned 0 devices");
 }
 
+int nbx_warmup(int device) {
+    int ndev = 0;
+    int rc = nbx_device_count(&ndev);
+    if (rc != NBX_OK) return rc;
+    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));  // forces runtime + context creation
+    // a 1-body evaluation loads the code object and touches every kernel of the default path
+    const double one[7] = {1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+    double f[3];
+    return nbx_brute_force_forces(one, 1, 3, sizeof one, NBX_REFERENCE_G, device, f, nullptr);
+}
+
 int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_shards, int shard) {
     if (!out) return fail(NBX_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -201,9 +214,8 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     CTX_TRY(hipMalloc((void**)&c->x64, (size_t)dim * pad * sizeof(double)));
     CTX_TRY(hipMalloc((void**)&c->v64, (size_t)dim * pad * sizeof(double)));
     CTX_TRY(hipMalloc((void**)&c->m64, pad * sizeof(double)));
-    c->ev0.resize(kEventPairs); c->ev1.resize(kEventPairs);
-    for (int i = 0; i < kEventPairs; ++i) { c->ev0[i] = nullptr; c->ev1[i] = nullptr; }
-    for (int i = 0; i < kEventPairs; ++i) { CTX_TRY(hipEventCreate(&c->ev0[i])); CTX_TRY(hipEventCreate(&c->ev1[i])); }
+    c->ev0.assign(kEventPairs, nullptr);  // event pairs are created on first use
+    c->ev1.assign(kEventPairs, nullptr);
 #undef CTX_TRY
     *out = c;
     return NBX_OK;
@@ -356,6 +368,10 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     else { L.chunk_first = 0; L.vchunks = c->n_shards - 1; L.chunk_skip = c->shard; L.accumulate = 1; }
     if (L.vchunks == 0) return NBX_OK;  // REMOTE with a single shard: nothing to add
     const bool timed = !c->capturing && c->ev_used < kEventPairs;
+    if (timed && !c->ev0[c->ev_used]) {
+        HIP_TRY(hipEventCreate(&c->ev0[c->ev_used]));
+        HIP_TRY(hipEventCreate(&c->ev1[c->ev_used]));
+    }
     if (timed) { L.ev_start = c->ev0[c->ev_used]; L.ev_stop = c->ev1[c->ev_used]; }
     HIP_TRY(launch_accel(c->dim, L, c->stream));
     if (timed) ++c->ev_used;

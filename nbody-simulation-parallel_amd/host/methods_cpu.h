@@ -9,8 +9,12 @@
 
 #include <vector>
 
-#include "body.h"
+#if __has_include("nbody_types.h")
+#include "nbody_types.h"  // this repository's layout-locked Vector<D> / Body<D>
+#else
+#include "body.h"  // inside the reference tree: the reference's own types (same memory)
 #include "vector.h"
+#endif
 
 template <int D> std::vector<Vector<D>> brute_force_seq_n_body(const std::vector<Body<D>>& bodies);
 template <int D> std::vector<Vector<D>> brute_force_omp_n_body_1(const std::vector<Body<D>>& bodies);

@@ -34,6 +34,12 @@ int device_ordinal() {
 }  // namespace
 
 const HipRunInfo& last_hip_run_info() { return g_info; }
+bool warm_up_hip() {
+    bool ok = true;
+    if (g_devices.size() > 1) for (int d : g_devices) ok = (nbx_warmup(d) == NBX_OK) && ok;
+    else ok = nbx_warmup(device_ordinal()) == NBX_OK;
+    return ok;
+}
 void set_hip_device(int device) { g_device = device; }
 void set_hip_devices(const std::vector<int>& devices) { g_devices = devices; }
 

@@ -10,8 +10,12 @@
 
 #include <vector>
 
-#include "body.h"
+#if __has_include("nbody_types.h")
+#include "nbody_types.h"  // this repository's layout-locked Vector<D> / Body<D>
+#else
+#include "body.h"  // inside the reference tree: the reference's own types (same memory)
 #include "vector.h"
+#endif
 
 // Same contract as brute_force_seq_n_body<D> / brute_force_omp_n_body_{1,2}<D>: forces (not
 // accelerations) on every body under the reference's law, F_i = -G m_i sum_j m_j (p_j-p_i)/r^4 with
@@ -52,6 +56,10 @@ struct HipRunInfo {
     int device = 0;
 };
 const HipRunInfo& last_hip_run_info();
+
+// Bring the device(s) up before anything is timed (HIP runtime, code-object load): nbx_warmup.
+// Returns false (and changes nothing) if no device is usable -- the solver calls will then throw.
+bool warm_up_hip();
 
 // Device ordinal used by the two entry points above (default 0; NBODY_HIP_DEVICE overrides).
 void set_hip_device(int device);

@@ -1,9 +1,10 @@
-// vector.h -- D-component fp64 vector, layout-locked to the reference's Vector<D>
-// (nbody-sim-new/vector.h:9-12: one std::array<double, D> member named `components`, no padding).
-// Written from scratch for this repository's host code; when methods_hip.h is dropped into the
-// reference tree, the reference's own vector.h is used instead (same names, same memory).
-#ifndef NBODY_AMD_VECTOR_H
-#define NBODY_AMD_VECTOR_H
+// nbody_types.h -- the two value types of the hot path, layout-locked to the reference's:
+//   Vector<D>: D packed doubles (nbody-sim-new/vector.h:9-12: one std::array<double, D> member `components`)
+//   Body<D>  : position, velocity, mass (nbody-sim-new/body.h:8-11): 56 B for D=3, 40 B for D=2, no padding
+// Written from scratch for this repository's host code.  When methods_hip.h is dropped into the reference
+// tree this header is absent and the reference's own body.h / vector.h are used (same names, same memory).
+#ifndef NBODY_AMD_TYPES_H
+#define NBODY_AMD_TYPES_H
 
 #include <array>
 #include <cmath>
@@ -61,4 +62,26 @@ using Vector3D = Vector<3>;
 
 static_assert(sizeof(Vector<2>) == 16 && sizeof(Vector<3>) == 24, "Vector<D> must be D packed doubles");
 
-#endif  // NBODY_AMD_VECTOR_H
+
+// ---- Body<D>: the memory the C ABI (include/nbody_hip.h) reads and writes -----------------------------
+
+
+template <int D>
+struct Body {
+    Vector<D> position;
+    Vector<D> velocity;
+    double mass = 0.0;
+
+    Body() = default;
+    Body(const Vector<D>& p, double m) : position(p), mass(m) {}
+    Body(const Vector<D>& p, const Vector<D>& v, double m) : position(p), velocity(v), mass(m) {}
+};
+
+using Body2D = Body<2>;
+using Body3D = Body<3>;
+
+static_assert(sizeof(Body<3>) == 56 && offsetof(Body<3>, velocity) == 24 && offsetof(Body<3>, mass) == 48, "Body<3> layout");
+static_assert(sizeof(Body<2>) == 40 && offsetof(Body<2>, velocity) == 16 && offsetof(Body<2>, mass) == 32, "Body<2> layout");
+
+
+#endif  // NBODY_AMD_TYPES_H

@@ -19,8 +19,12 @@
 #include <string>
 #include <vector>
 
-#include "body.h"
+#if __has_include("nbody_types.h")
+#include "nbody_types.h"  // this repository's layout-locked Vector<D> / Body<D>
+#else
+#include "body.h"  // inside the reference tree: the reference's own types (same memory)
 #include "vector.h"
+#endif
 
 // utils.h:21-27
 constexpr double G = 4.471e-21;
