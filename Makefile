@@ -51,7 +51,8 @@ oracle:
 	$(MAKE) -C oracle
 
 HOST_SRCS := $(wildcard $(PKG)/host/*.cpp)
-nbody_sim: $(LIB) $(HOST_SRCS)
+HOST_HDRS := $(wildcard $(PKG)/host/*.h) include/nbody_hip.h
+nbody_sim: $(LIB) $(HOST_SRCS) $(HOST_HDRS)
 	@if [ -n "$(HOST_SRCS)" ]; then \
 	  $(CXX) $(CXXFLAGS) $(HOST_SRCS) -o $@ $(LDFLAGS) -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/$(PKG)'; \
 	else echo "host harness not built yet"; fi
