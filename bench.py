@@ -126,10 +126,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): NBODY_BENCH_BACKEND=gloo stages the exchange through host memory
+    # and NBODY_BENCH_DEVICE=<i> puts every rank on one GPU, so the N > 1 code path can run on a single-GPU box.
+    backend = os.environ.get("NBODY_BENCH_BACKEND", "nccl")
+    if "NBODY_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["NBODY_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # synthetic bodies, identical on every rank (the reference generator's stream, seeded)
     bodies = nbx.uniform_bodies(args.bodies, args.dim, args.seed)
@@ -156,7 +164,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms, launches = be.kernel_time()  # HIP events on the stream the kernels ran on
