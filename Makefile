@@ -57,14 +57,14 @@ nbody_sim: $(LIB) $(HOST_SRCS) $(HOST_HDRS)
 	  $(CXX) $(CXXFLAGS) $(HOST_SRCS) -o $@ $(LDFLAGS) -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/$(PKG)'; \
 	else echo "host harness not built yet"; fi
 
-tools/bench_force: tools/bench_force.cpp $(LIB)
-	$(CXX) -std=c++17 -O2 -Iinclude $< -o $@ -L$(PKG) -lnbody_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
-
 tools/ubench_valu: tools/ubench_valu.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 
+tools/ubench_banks: tools/ubench_banks.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
+
 clean:
-	rm -f $(OBJS) $(LIB) nbody_sim tools/bench_force tools/ubench_valu
+	rm -f $(OBJS) $(LIB) nbody_sim tools/ubench_valu tools/ubench_banks
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean
