@@ -117,3 +117,11 @@ def test_energy_matches_force_law(oracle):
         bm[i, k] -= h
         dU = (oracle.energy(bp)[1] - oracle.energy(bm)[1]) / (2 * h)
         assert abs(-dU - f[i, k]) <= 1e-6 * abs(f[i, k])
+
+
+def test_oracle_under_sanitizers():
+    """make -C oracle asan-check: every oracle entry point on small/degenerate inputs under ASan + UBSan."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan-check"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "oracle selftest ok" in p.stdout, p.stdout + p.stderr
