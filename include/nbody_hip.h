@@ -124,8 +124,9 @@ int nbx_ctx_compute_accel(nbx_ctx* ctx, int which);
 int nbx_ctx_kick_drift(nbx_ctx* ctx, double G, double dt);
 
 /* nsteps x { compute_accel(ALL); kick_drift } -- single-shard contexts only (n_shards == 1).  From 4 steps
- * on, one step is captured into a hipGraph and replayed (launch-bound regime at small N); the per-kernel
- * event log of nbx_ctx_kernel_time then has no samples for those steps.  NBODY_HIP_NO_GRAPHS=1 disables it. */
+ * on, one step is captured into a hipGraph and replayed (launch-bound regime at small N); nbx_ctx_kernel_time
+ * then reports those steps by their whole-step time (one event pair around the replay sequence).
+ * NBODY_HIP_NO_GRAPHS=1 disables the capture. */
 int nbx_ctx_step(nbx_ctx* ctx, double G, double dt, int nsteps);
 
 /* Forces of this shard's targets as Vector<dim>[shard_len] doubles: F_i = -(G m_i) a_i.

@@ -38,6 +38,11 @@ struct nbx_ctx {
     int graph_variant = -1, graph_splits = 0;
     hipStream_t graph_stream = nullptr;
     bool capturing = false;
+    // timing of graph-replayed steps: one event pair around a whole replay sequence
+    hipEvent_t bulk0 = nullptr, bulk1 = nullptr;
+    int bulk_steps = 0;          // steps covered by the pending (bulk0, bulk1) pair
+    double bulk_ms_done = 0.0;   // already-resolved replay time not yet reported
+    int bulk_steps_done = 0;
     bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
     int close_list_valid = 0;   // the device list matches the positions in pos_all
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
