@@ -332,3 +332,33 @@ def test_signed_and_extreme_coordinates(nbx, oracle):
             c.set_tuning(0, v)
             c.compute_accel()
             assert_force_parity(c.forces(oracle.G), ref, S, f"signed coordinates, {c.effective_tuning()[0]}")
+
+
+@pytest.mark.parametrize("kind", ("blobs", "lattice", "plane", "masses", "tiny_box_offset"))
+def test_structured_distributions(nbx, oracle, kind):
+    """Inputs that are not uniform-random: clustered bodies, a lattice (many equal distances and exact
+    duplicates), a system confined to a plane (dz = 0 everywhere), masses spread over 12 decades, and a small
+    box far from the origin (large coordinates, small separations: the regime where fp32 input rounding bites,
+    hence the oracle on the rounded inputs)."""
+    rng = np.random.default_rng(17)
+    n, dim = 3000, 3
+    b = oracle.generate(40, n, dim)
+    if kind == "blobs":
+        centres = rng.uniform(1e6, 9e6, size=(6, 3))
+        b[:, :3] = centres[rng.integers(0, 6, n)] + rng.normal(scale=2.0e3, size=(n, 3))
+    elif kind == "lattice":
+        g = np.stack(np.meshgrid(*[np.arange(15)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n].astype(float)
+        b[:, :3] = 1.0e6 + 512.0 * g
+        b[7, :3] = b[8, :3]
+    elif kind == "plane":
+        b[:, 2] = 4.0e6
+    elif kind == "masses":
+        b[:, -1] = 10.0 ** rng.uniform(-4, 8, n)
+    elif kind == "tiny_box_offset":
+        b[:, :3] = 8.0e6 + rng.uniform(0, 5.0e3, size=(n, 3))
+    b = oracle.round_inputs_to_f32(b)
+    ref = oracle.brute_force_seq(b)
+    S = oracle.force_magnitude_sums(b)
+    f = nbx.brute_force_hip_n_body(b, oracle.G)
+    assert_force_parity(f, ref, S, kind)
+    assert oracle.compute_accuracy(f, ref) == 100.0 or kind in ("lattice",)   # symmetric lattices have exactly cancelling components
