@@ -152,10 +152,11 @@ int nbx_ctx_synchronize(nbx_ctx* ctx);
 /* Tuning knobs.  source_splits: number of slices the source loop is cut into (0 = automatic, else a
  * lower bound in [1,256]; more workgroups for small shards; partial sums are combined in a fixed
  * order).  variant: force-kernel variant id in [0, nbx_num_variants()), -1 = library default (see
- * DESIGN.md for the table).  "fast" variants drop the per-pair r^2 guard and evaluate the few targets
- * that could own a sub-threshold pair with the guarded kernel, so the result keeps the reference's
- * skip semantics; when their preconditions fail (a mass above 1e10, or most of the shard within
- * 8192 of a coordinate plane) the library substitutes the guarded default. */
+ * DESIGN.md for the table).  "fast" variants drop the per-pair r^2 guard, find the targets that own a
+ * pair closer than 1e-3 exactly (candidates = a coordinate below 16384 in magnitude, checked against each
+ * other once per position update) and evaluate those with the guarded kernel inside the same launch, so the
+ * result keeps the reference's skip semantics; when their preconditions fail (a mass above 1e10, or more than
+ * 1/8 of the shard in the candidate set) the library substitutes the guarded default. */
 int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
 /* The variant and slice count the next force evaluation will use (after upload). */
 int nbx_ctx_effective_tuning(nbx_ctx* ctx, int* variant, int* source_splits);
