@@ -20,17 +20,20 @@ constexpr float kR2SkipF = 1.0e-10f;
 static_assert((double)kR2SkipF >= 1e-10, "fp32 threshold must not round below the fp64 one");
 
 // ---- close-pair bookkeeping of the fast force path (force_kernel.hip) --------------------------------
-// The fast kernel carries no per-pair guard: it biases r^2 by kTiny so that coincident bodies (d = 0)
-// contribute exactly 0 and 1/r^2 stays finite.  That is exact unless a target has a source with
-// 0 < r^2 < kBadR2 (there the bias, or the reference's skip rule r^2 < 1e-10, would matter; for
-// r^2 >= kBadR2 = 1e-6 the bias kTiny = 2^-47 moves r^2 by < 1e-8 relative, far below half an ulp).
-// Such "bad" targets are found exactly, once per position update, in two cheap steps:
-//  1. candidates: two DISTINCT fp32 coordinates a, b differ by at least the fp32 spacing at
-//     min(|a|,|b|), so a pair with 0 < r^2 < 1e-6 (every |d_k| < 1e-3, some d_k != 0) has both members
-//     with a coordinate of magnitude < 2^14 in that dimension.  classify_close_kernel lists the
-//     targets with any |coordinate| < kCloseCoord = 16384 (0.5 % of the reference's uniform bodies);
-//  2. refine_close_kernel checks the candidates against each other (all-pairs over the small list,
-//     the same fp32 r^2) and keeps those that really have a partner with 0 < r^2 < kBadR2 -- almost
+// The fast kernel carries no per-pair guard: it biases r^2 by kTiny = 2^-47 so that coincident bodies
+// (d = 0) contribute exactly 0 and 1/r^2 stays finite.  That reproduces the reference for a target unless
+// it has a source with 0 < r^2 < X, where X = max(1e-10 [the reference's skip threshold, methods.cpp:24],
+// 2^25 * kTiny = 2.4e-7 [below this the bias moves r^2 by more than half a unit roundoff]) = 2.4e-7.
+// Targets that might own such a pair are found exactly, once per position update, in two cheap steps:
+//  1. candidates.  Two DISTINCT fp32 coordinates a, b of equal sign differ by at least the fp32 spacing at
+//     min(|a|,|b|) (opposite signs: by |a|+|b|).  A pair with 0 < r^2 < 2.4e-7 has some |d_k| in (0, 4.9e-4),
+//     hence min(|a_k|,|b_k|) < 2^13 and max < 2^13 + 4.9e-4: BOTH members have a coordinate of magnitude below
+//     kCloseCoord = 2^14 (twice what the argument needs).  classify_close_kernel lists the shard's targets with
+//     any |coordinate| < kCloseCoord (0.5 % of the reference's uniform bodies).  Conversely a non-candidate
+//     differs from every other body, in each coordinate where they differ, by >= 2^-10, so its non-zero r^2
+//     are >= 9.5e-7: never skipped by the reference and biased by < 1e-8 relative.
+//  2. refine_close_kernel checks the candidates against each other (all-pairs over the small list, the
+//     same fp32 r^2) and keeps those with a partner at 0 < r^2 < kBadR2 = 1e-6 (4x the X above) -- almost
 //     always none.  Above kRefineLimit candidates it keeps them all.
 // Bad targets are flagged (the fast kernel does not store them) and evaluated with the exact
 // compare-and-select guard by extra workgroups of the same launch (close_set_path), then scattered
