@@ -362,3 +362,32 @@ def test_structured_distributions(nbx, oracle, kind):
     f = nbx.brute_force_hip_n_body(b, oracle.G)
     assert_force_parity(f, ref, S, kind)
     assert oracle.compute_accuracy(f, ref) == 100.0 or kind in ("lattice",)   # symmetric lattices have exactly cancelling components
+
+
+def test_fast_path_boundary_pairs(nbx, oracle):
+    """Pairs sitting exactly on the thresholds of the close-set argument: one fp32 step apart across 8192 and
+    across 16384 (candidate / non-candidate split), and sub-threshold neighbours just inside the candidate
+    region -- every one must come out like the reference's guarded sum."""
+    n, dim = 4096, 3
+    b = oracle.generate(55, n, dim)
+    f32 = np.float32
+    def below(x):
+        return float(np.nextafter(f32(x), f32(0)))
+    b[10, :3] = (below(8192.0), 5.0e6, 5.0e6);  b[11, :3] = (8192.0, 5.0e6, 5.0e6)         # d = 4.88e-4
+    b[20, :3] = (below(16384.0), 6.0e6, 6.0e6); b[21, :3] = (16384.0, 6.0e6, 6.0e6)       # d = 9.77e-4: 21 is no candidate
+    b[30, :3] = (7.0e6, below(16384.0), 7.0e6); b[31, :3] = (7.0e6, 16384.0, 7.0e6)       # same in y
+    b[40, :3] = (100.0, 100.0, 100.0);          b[41, :3] = (100.0 + 7.63e-6, 100.0, 100.0)  # r^2 = 5.8e-11 -> skipped
+    b[50, :3] = (-3000.0, 2.0e6, 2.0e6);        b[51, :3] = (-3000.0 - 2.4414e-4, 2.0e6, 2.0e6)  # negative side, counted
+    b = oracle.round_inputs_to_f32(b)
+    ref = oracle.brute_force_seq(b)
+    S = oracle.force_magnitude_sums(b)
+    for v, name in _fast_variants(nbx)[:3] + [(-1, "default")]:
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.set_tuning(0, v)
+            c.compute_accel()
+            f = c.forces(oracle.G)
+        assert_force_parity(f, ref, S, f"boundary pairs, {name}")
+        for i in (10, 11, 20, 21, 30, 31, 50, 51):       # dominated by the partner: compare directly
+            assert np.allclose(f[i], ref[i], rtol=2e-5, atol=0), (name, i)
+        assert np.allclose(f[40], ref[40], rtol=1e-4) and np.allclose(f[41], ref[41], rtol=1e-4)
