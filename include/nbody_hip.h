@@ -132,6 +132,11 @@ int nbx_ctx_step(nbx_ctx* ctx, double G, double dt, int nsteps);
 /* Forces of this shard's targets as Vector<dim>[shard_len] doubles: F_i = -(G m_i) a_i.
  * Synchronises the stream. */
 int nbx_ctx_get_forces(nbx_ctx* ctx, double G, double* forces_out);
+/* The reference's accuracy metric (utils.h:170-219, ACCURACY_PCT_THRESHOLD 1 %, ACCURACY_FORCE_THRESHOLD 1e-20)
+ * evaluated on the device against reference_forces (host, Vector<dim>[shard_len] of this shard): percent of
+ * bodies whose every force component is within 1 % (absolute 1e-9 where |ref| < 1e-20).  The device forces are
+ * never copied back; 4 bytes return.  Synchronises the stream. */
+int nbx_ctx_accuracy(nbx_ctx* ctx, double G, const double* reference_forces, double* percent);
 /* Raw fp32 accelerations, SoA float[dim][shard_len].  Synchronises the stream. */
 int nbx_ctx_get_accel(nbx_ctx* ctx, float* accel_out);
 /* Write this shard's positions and velocities (fp64 state) back into the caller's full-length

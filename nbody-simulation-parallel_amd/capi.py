@@ -45,6 +45,7 @@ ABI = [
     ("nbx_ctx_kick_drift", _i, [_vp, _d, _d]),
     ("nbx_ctx_step", _i, [_vp, _d, _d, _i]),
     ("nbx_ctx_get_forces", _i, [_vp, _d, _vp]),
+    ("nbx_ctx_accuracy", _i, [_vp, _d, _vp, _pd]),
     ("nbx_ctx_get_accel", _i, [_vp, _vp]),
     ("nbx_ctx_download_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_ctx_energy", _i, [_vp, _d, _pd, _pd]),
@@ -231,6 +232,16 @@ class Context:
         out = np.empty((self.count, self.dim), dtype=np.float64)
         self._ck(self.lib.nbx_ctx_get_forces(self.h, G, out.ctypes.data), "nbx_ctx_get_forces")
         return out
+
+    def accuracy(self, reference_forces: np.ndarray, G: float = REFERENCE_G) -> float:
+        """Percent of this shard's bodies within the reference's 1 % rule of reference_forces (utils.h:170-219),
+        computed on the device."""
+        r = np.ascontiguousarray(reference_forces, dtype=np.float64)
+        if r.shape != (self.count, self.dim):
+            raise ValueError("reference_forces must be [count, dim]")
+        pct = ctypes.c_double(0.0)
+        self._ck(self.lib.nbx_ctx_accuracy(self.h, G, r.ctypes.data, ctypes.byref(pct)), "nbx_ctx_accuracy")
+        return pct.value
 
     def accel(self) -> np.ndarray:
         out = np.empty((self.dim, self.count), dtype=np.float32)

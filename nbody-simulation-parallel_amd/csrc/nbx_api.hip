@@ -473,6 +473,24 @@ int nbx_ctx_get_forces(nbx_ctx* c, double G, double* out) {
     return NBX_OK;
 }
 
+int nbx_ctx_accuracy(nbx_ctx* c, double G, const double* reference_forces, double* percent) {
+    if (!c || !percent || (!reference_forces && c->count)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->have_accel) return fail(NBX_ERR_STATE, "no accelerations computed");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t bytes = c->count * c->dim * sizeof(double);
+    rc = ensure_stage(c, bytes + 16);
+    if (rc) return rc;
+    unsigned* counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->stage) + bytes);  // 8-byte aligned tail
+    if (bytes) HIP_TRY(hipMemcpyAsync(c->stage, reference_forces, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_accuracy(c->acc, c->splits, c->dim, c->pad, c->count, G, c->m64, c->stage, counter, c->stream));
+    unsigned good = 0;
+    HIP_TRY(hipMemcpyAsync(&good, counter, sizeof good, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *percent = c->count ? 100.0 * (double)(int)good / (double)c->count : 0.0;
+    return NBX_OK;
+}
+
 int nbx_ctx_get_accel(nbx_ctx* c, float* out) {
     if (!c || (!out && c->count)) return fail(NBX_ERR_INVALID, "null argument");
     if (!c->have_accel) return fail(NBX_ERR_STATE, "no accelerations computed");

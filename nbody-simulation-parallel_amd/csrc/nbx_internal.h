@@ -157,6 +157,9 @@ hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned p
 // energy_out: double[2][count]: per-body kinetic m v^2 / 2 and potential (G m / 4) * sum_slices phi
 hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned pad, size_t count, double G,
                                 const double* v64, const double* m64, double* energy_out, hipStream_t stream);
+// *accurate = number of bodies whose force is within the reference's 1 % rule of ref_forces (device AoS double[count][dim])
+hipError_t launch_accuracy(const float* acc, int splits, int dim, unsigned pad, size_t count, double G,
+                           const double* m64, const double* ref_forces, unsigned* accurate, hipStream_t stream);
 // state_out: AoS double[count][2*dim] = position then velocity
 hipError_t launch_export_state(const double* x64, const double* v64, int dim, unsigned pad, size_t count,
                                double* state_out, hipStream_t stream);

@@ -105,6 +105,27 @@ __global__ __launch_bounds__(256) void export_energy_kernel(const float* __restr
     out[count + l] = 0.25 * G * m * p;
 }
 
+// The reference's accuracy metric (nbody-sim-new/utils.h:170-219) on the device: a body counts as accurate
+// when every force component is within 1 % of the reference's; components with |ref| < 1e-20 are held to
+// |f| <= 1e-9 instead.  F = -(G m) a is formed exactly as export_forces_kernel does.
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* __restrict__ acc, int splits, int dim, unsigned pad,
+                                                       size_t count, double G, const double* __restrict__ m64,
+                                                       const double* __restrict__ ref, unsigned* __restrict__ accurate) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool ok = l < count;
+    if (ok) {
+        const double gm = G * m64[l];
+        for (int k = 0; k < dim && ok; ++k) {
+            const double f = -(gm * sum_partials(acc, splits, dim, pad, k, l));
+            const double r = ref[l * dim + k];
+            if (fabs(r) < 1e-20) ok = !(fabs(f) > 1e-9);
+            else ok = !(fabs((f - r) / r) > 0.01);
+        }
+    }
+    const unsigned long long votes = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && votes) atomicAdd(accurate, (unsigned)__popcll(votes));
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -143,6 +164,15 @@ hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned 
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(export_energy_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, phi, splits, dim, pad, count,
                        G, v64, m64, energy_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_accuracy(const float* acc, int splits, int dim, unsigned pad, size_t count, double G,
+                           const double* m64, const double* ref_forces, unsigned* accurate, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(accurate, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess || count == 0) return e;
+    hipLaunchKernelGGL(accuracy_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, acc, splits, dim, pad, count, G,
+                       m64, ref_forces, accurate);
     return hipGetLastError();
 }
 

@@ -391,3 +391,27 @@ def test_fast_path_boundary_pairs(nbx, oracle):
         for i in (10, 11, 20, 21, 30, 31, 50, 51):       # dominated by the partner: compare directly
             assert np.allclose(f[i], ref[i], rtol=2e-5, atol=0), (name, i)
         assert np.allclose(f[40], ref[40], rtol=1e-4) and np.allclose(f[41], ref[41], rtol=1e-4)
+
+
+def test_device_side_accuracy_metric(nbx, oracle):
+    """nbx_ctx_accuracy = the reference's compute_accuracy (utils.h:170-219) without copying the forces back."""
+    n, dim = 5000, 3
+    b = _oracle_inputs(oracle, 61, n, dim)
+    ref = oracle.brute_force_seq(b)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.compute_accel()
+        f = c.forces(oracle.G)
+        assert c.accuracy(ref, oracle.G) == 100.0 == oracle.compute_accuracy(f, ref)
+        noisy = ref.copy()
+        noisy[::7, 1] *= 1.02                      # 2 % off in one component of every 7th body
+        noisy[3, 0] = 1e-25                        # tiny reference component: absolute rule, still accurate
+        want = oracle.compute_accuracy(f, noisy)
+        assert 80.0 < want < 90.0
+        assert c.accuracy(noisy, oracle.G) == want
+    for r in range(2):                             # shards compare their own slice
+        with nbx.Context(n, dim, n_shards=2, shard=r) as c:
+            c.upload(b)
+            c.compute_accel()
+            lo = r * c.shard_len
+            assert c.accuracy(ref[lo:lo + c.count], oracle.G) == 100.0
