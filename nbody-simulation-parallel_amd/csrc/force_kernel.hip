@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void classify_close_kernel(KArgs a) {
 }
 
 // Candidates against candidates: keep those with a partner at 0 < r^2 < kBadR2 (see nbx_internal.h).
-// Fixed grid, grid-stride over blocks of 256 candidates; the candidate positions stream through LDS.
+// Fixed grid, grid-stride over (target block, source block) pairs of 256 candidates each, so the check of a
+// few thousand candidates spreads over the chip instead of running as a handful of long workgroups; a target
+// found bad by several workgroups is listed once (atomicExch on its flag).
 template <int D>
 __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
     __shared__ float tx[256], ty[256], tz[256];
@@ -358,35 +360,33 @@ __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
     const unsigned n = a.counters[0];
     const unsigned nblk = (n + 255u) / 256u;
     const bool keep_all = n > kRefineLimit;
-    for (unsigned tb = blockIdx.x; tb < nblk; tb += gridDim.x) {
+    const unsigned npairs = keep_all ? nblk : nblk * nblk;
+    for (unsigned p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const unsigned tb = keep_all ? p : p / nblk, sb = keep_all ? 0u : p - tb * nblk;
         const unsigned slot = tb * 256u + tid;
         const bool valid = slot < n;
         const unsigned ls = valid ? slot : 0;
         const float x = a.cand_pos[ls], y = a.cand_pos[(size_t)a.pad + ls], z = (D == 3) ? a.cand_pos[2 * (size_t)a.pad + ls] : 0.0f;
         bool bad = keep_all;
         if (!keep_all) {
-            for (unsigned sb = 0; sb < nblk; ++sb) {
-                const unsigned j = sb * 256u + tid;
-                __syncthreads();
-                // out-of-range entries duplicate this lane's own position: r^2 = 0, never "bad"
-                tx[tid] = (j < n) ? a.cand_pos[j] : x;
-                ty[tid] = (j < n) ? a.cand_pos[(size_t)a.pad + j] : y;
-                tz[tid] = (D == 3 && j < n) ? a.cand_pos[2 * (size_t)a.pad + j] : z;
-                __syncthreads();
-                const unsigned lim = (n - sb * 256u < 256u) ? n - sb * 256u : 256u;
-                for (unsigned k = 0; k < lim; ++k) {
-                    const float dx = tx[k] - x, dy = ty[k] - y;
-                    float r2 = __builtin_fmaf(dy, dy, dx * dx);
-                    if (D == 3) { const float dz = tz[k] - z; r2 = __builtin_fmaf(dz, dz, r2); }
-                    bad = bad || (r2 > 0.0f && r2 < kBadR2);
-                }
+            const unsigned j = sb * 256u + tid;
+            __syncthreads();
+            // out-of-range entries duplicate this lane's own position: r^2 = 0, never "bad"
+            tx[tid] = (j < n) ? a.cand_pos[j] : x;
+            ty[tid] = (j < n) ? a.cand_pos[(size_t)a.pad + j] : y;
+            tz[tid] = (D == 3 && j < n) ? a.cand_pos[2 * (size_t)a.pad + j] : z;
+            __syncthreads();
+            const unsigned lim = (n - sb * 256u < 256u) ? n - sb * 256u : 256u;
+            for (unsigned k = 0; k < lim; ++k) {
+                const float dx = tx[k] - x, dy = ty[k] - y;
+                float r2 = __builtin_fmaf(dy, dy, dx * dx);
+                if (D == 3) { const float dz = tz[k] - z; r2 = __builtin_fmaf(dz, dz, r2); }
+                bad = bad || (r2 > 0.0f && r2 < kBadR2);
             }
         }
         if (valid && bad) {
             const unsigned i = a.cand_list[slot];
-            const unsigned b = atomicAdd(&a.counters[1], 1u);
-            a.bad_list[b] = i;
-            a.bad_flag[i] = 1;
+            if (atomicExch(&a.bad_flag[i], 1u) == 0u) a.bad_list[atomicAdd(&a.counters[1], 1u)] = i;
         }
     }
 }

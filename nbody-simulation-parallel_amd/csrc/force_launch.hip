@@ -86,11 +86,11 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     const int di = dim - 2;
     if (V.fast && !(L.close_list_valid && *L.close_list_valid)) {  // (re)build the bad-target list for these positions
         if ((e = hipMemsetAsync(L.counters, 0, 2 * sizeof(unsigned), stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(L.bad_flag, 0, L.pad, stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(L.bad_flag, 0, (size_t)L.pad * sizeof(unsigned), stream)) != hipSuccess) return e;
         if (L.count) {
             hipLaunchKernelGGL(table().ck.classify[di], dim3((L.count + 255u) / 256u, 1, 1), block, 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
-            hipLaunchKernelGGL(table().ck.refine[di], dim3(256, 1, 1), block, 0, stream, a);
+            hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (L.close_list_valid) *L.close_list_valid = 1;

@@ -112,7 +112,7 @@ int ensure_acc(nbx_ctx* c) {
             HIP_TRY(hipMalloc((void**)&c->cand_list, (size_t)c->pad * sizeof(unsigned)));
             HIP_TRY(hipMalloc((void**)&c->cand_pos, (size_t)c->dim * c->pad * sizeof(float)));
             HIP_TRY(hipMalloc((void**)&c->bad_list, (size_t)c->pad * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->bad_flag, (size_t)c->pad));
+            HIP_TRY(hipMalloc((void**)&c->bad_flag, (size_t)c->pad * sizeof(unsigned)));
             HIP_TRY(hipMalloc((void**)&c->counters, 2 * sizeof(unsigned)));
             c->close_list_valid = 0;
         }

@@ -27,7 +27,7 @@ struct nbx_ctx {
     unsigned* cand_list = nullptr;
     float* cand_pos = nullptr;
     unsigned* bad_list = nullptr;
-    unsigned char* bad_flag = nullptr;
+    unsigned* bad_flag = nullptr;
     unsigned* counters = nullptr;
     float* close_acc = nullptr;
     int close_splits_alloc = 0;

@@ -64,7 +64,7 @@ struct AccelLaunch {
     unsigned* cand_list;      // [pad] candidate target indices
     float* cand_pos;          // [dim][pad] their positions, compacted
     unsigned* bad_list;       // [pad] targets that own a pair with 0 < r^2 < kBadR2
-    unsigned char* bad_flag;  // [pad] 1 for listed targets
+    unsigned* bad_flag;  // [pad] 1 for listed targets
     unsigned* counters;       // [0] = candidates, [1] = bad targets
     float* close_acc;         // [splits][dim][pad]
     int* close_list_valid;    // host flag owned by the context: lists match the current positions
@@ -89,7 +89,7 @@ struct KArgs {
     unsigned* __restrict__ cand_list;
     float* __restrict__ cand_pos;
     unsigned* __restrict__ bad_list;
-    unsigned char* __restrict__ bad_flag;
+    unsigned* __restrict__ bad_flag;
     unsigned* __restrict__ counters;
     float* __restrict__ close_acc;
 };
