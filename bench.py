@@ -30,14 +30,53 @@ PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = FP3
 HBM_PEAK_GBPS = 8000.0
 
 
-def cpu_baseline(n_bodies, dim, seed, budget_s=12.0):
+def host_facts():
+    """CPU model / sockets / cores of this box (lscpu) and how many hardware threads this process may use."""
+    import subprocess
+    facts = {}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "CPU(s)", "Thread(s) per core", "Core(s) per socket", "Socket(s)"):
+                facts[k.strip()] = v.strip()
+    except OSError:
+        pass
+    facts["usable_hw_threads"] = len(os.sched_getaffinity(0))
+    try:
+        phys = int(facts["Core(s) per socket"]) * int(facts["Socket(s)"])
+    except (KeyError, ValueError):
+        phys = facts["usable_hw_threads"]
+    facts["physical_cores_usable"] = max(1, min(phys, facts["usable_hw_threads"]))
+    return facts
+
+
+def cpu_baseline_child(threads, n_s, dim, seed):
+    """Child process of cpu_baseline(): OpenMP / ParlayLib size their pools at start-up, so every thread count
+    runs in a fresh process (env set by the parent).  Prints one JSON line per reference solver."""
+    import numpy as np
+    import nbody_amd as nbx
+    from oracle_lib import Reference
+    ref = Reference()
+    sub = np.ascontiguousarray(nbx.uniform_bodies(n_s, dim, seed))
+    for v, name in ((2, "brute_force_omp_n_body_2"), (1, "brute_force_omp_n_body_1")):
+        dt = ref.time_brute_force(v, sub)
+        print(json.dumps({"solver": f"{name}<{dim}>", "threads": threads, "n": n_s, "seconds": dt,
+                          "value": n_s * (n_s - 1) / dt}), flush=True)
+
+
+def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
     """Reported baseline (not the target): the reference's own brute_force_omp_n_body_2 object code
     (oracle/_ref, kind "reference") or the oracle port of it (kind "port") on a bounded sample of
-    the same workload, timed on this host's cores."""
+    the same workload, timed on this host's cores: at 16 threads (the box's CPU share for one GPU, the primary
+    figure) and, when the process may use more, on all physical cores (also omp_1, the reference's faster
+    symmetric variant).  value = ordered pair interactions/s (N(N-1) per evaluation for every solver, so the
+    figures compare with the GPU's; the symmetric omp_1 evaluates half as many pairs)."""
+    import subprocess
     import numpy as np
-    from oracle_lib import Oracle, Reference, have_reference
+    from oracle_lib import Oracle, have_reference
     o = Oracle()
     threads = o.num_threads()
+    host = host_facts()
     bodies = o.generate(seed, n_bodies, dim)
     # calibrate with the port on a few rows, then size the sample for ~budget_s
     rows = np.arange(0, 2048, dtype=np.int64)
@@ -46,16 +85,23 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=12.0):
     rate = rows.size * n_bodies / (time.perf_counter() - t0)
     if have_reference():
         try:
-            ref = Reference()
             n_s = int(min(n_bodies, max(4096, (rate * budget_s) ** 0.5)))
             n_s = 1 << (n_s.bit_length() - 1)
-            sub = np.ascontiguousarray(bodies[:n_s])
-            t0 = time.perf_counter()
-            ref.brute_force(2, sub)
-            dt = time.perf_counter() - t0
-            return {"value": n_s * (n_s - 1) / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "reference",
-                    "sample": f"reference brute_force_omp_n_body_2<{dim}> object code (oracle/_ref) on the first {n_s} bodies "
-                              f"of the workload, {n_s*(n_s-1):.3e} pair evaluations in {dt:.2f} s, OMP_NUM_THREADS={threads}"}
+            runs = []
+            counts = [threads] + ([host["physical_cores_usable"]] if host["physical_cores_usable"] > threads else [])
+            for c in counts:
+                env = dict(os.environ, OMP_NUM_THREADS=str(c), PARLAY_NUM_THREADS=str(c), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(c), "--bodies", str(n_s),
+                                    "--dim", str(dim), "--seed", str(seed)], env=env, capture_output=True, text=True, timeout=600)
+                if p.returncode:
+                    raise RuntimeError(p.stderr[-300:])
+                runs += [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+            first = runs[0]
+            return {"value": first["value"], "unit": "pair-interactions/s", "cores": first["threads"], "kind": "reference",
+                    "sample": f"reference {first['solver']} object code (oracle/_ref) on the first {n_s} bodies of the workload, "
+                              f"{n_s*(n_s-1):.3e} ordered pairs in {first['seconds']:.2f} s, OMP_NUM_THREADS={first['threads']} "
+                              "(one GPU's share of the host)",
+                    "host": host, "all_runs": runs}
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"[bench] reference baseline unavailable ({e}); using the oracle port\n")
     nrows = int(min(n_bodies, max(2048, rate * budget_s / n_bodies)))
@@ -65,26 +111,32 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": nrows * (n_bodies - 1) / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "port",
             "sample": f"oracle port of brute_force_omp_n_body_2<{dim}>: {nrows} target rows x {n_bodies} sources "
-                      f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}"}
+                      f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}", "host": host}
 
 
-def accuracy_check(system, bodies, G, nrows=64):
-    """BASELINE metric, second half: max-abs / max-relative acceleration error of the device path against the
-    reference's sequential arithmetic (oracle rows in fp64 on the fp32-representable inputs), on sampled targets."""
+def accuracy_check(system, bodies, G, nrows=1024):
+    """BASELINE metric, second half (SURVEY 8d protocol: >= 1,024 sampled target rows at N >= 2^20, all rows below):
+    max-abs / max-relative acceleration error of the device path against the reference's arithmetic (oracle rows in
+    fp64 on the fp32-representable inputs).  max_rel_accel_err is the PLAIN maximum over all compared bodies."""
     import numpy as np
-    from oracle_lib import Oracle
+    from oracle_lib import KAPPA_WELL, Oracle, force_errors
     o = Oracle()
     n = bodies.shape[0]
     system.be.ctx.upload(bodies)  # back to the initial state (the timed steps moved the bodies)
     rounded = o.round_inputs_to_f32(bodies)
-    rows = np.unique(np.linspace(0, n - 1, nrows).astype(np.int64))
+    rows = np.arange(n) if n <= 65536 else np.unique(np.linspace(0, n - 1, nrows).astype(np.int64))
     ref = o.force_rows_omp_2(rounded, rows)
+    S = o.force_magnitude_sums(rounded, rows)
     system.compute_forces()
     f = system.forces(G)[rows]
     m = rounded[rows, -1][:, None]
     da = (f - ref) / m
     rel = np.sqrt((da ** 2).sum(1)) / np.sqrt(((ref / m) ** 2).sum(1))
+    e = force_errors(f, ref, S)
     return {"rows": int(rows.size), "max_abs_accel_err": float(np.abs(da).max()), "max_rel_accel_err": float(rel.max()),
+            "within_1e-5_relative": bool(rel.max() <= 1e-5), "n_over_1e-5": int((rel > 1e-5).sum()),
+            "n_ill": e["n_ill"], "ill_means": f"kappa = sum_j|f_ij| / |F_i| > {KAPPA_WELL:g}",
+            "max_backward_err": e["max_backward"], "max_abs_accel": float(np.abs(ref / m).max()),
             "reference": "oracle rows of brute_force_omp_n_body_2 in fp64 on the fp32-rounded inputs (= sequential path up to fp64 re-association)"}
 
 
@@ -100,7 +152,11 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="force-kernel variant id (-1: library default)")
     ap.add_argument("--splits", type=int, default=0, help="source slices (0: automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.cpu_baseline_child, args.bodies, args.dim, args.seed)
+        return
 
     import numpy as np
     import torch
@@ -154,15 +210,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # First contact with a multi-GPU node: before anything is timed, prove that the collective really moves the
+    # chunks -- every rank poisons the chunks it does not own, one exchange runs, and each remote chunk is compared
+    # on the host with the generated bodies (identical on every rank).  A mismatch ends the run non-zero.
+    exchange_check = None
+    if world > 1:
+        bad = system.verify_exchange(bodies)
+        exchange_check = {"mismatching_values": bad, "checked_values_per_rank": int(args.dim * (N - system.layout.count)),
+                          "transport": backend}
+        if bad:
+            sys.stderr.write(f"[bench] rank {rank}: position exchange FAILED its self-check: {bad} fp32 values differ from the "
+                             f"generated bodies after one {backend} all-gather\n")
+            dist.destroy_process_group()
+            sys.exit(3)
+
     for _ in range(args.warmup):
         system.step(args.dt, G, 1)
     sync_all()
     be.kernel_time()  # reset the force-kernel event log
+    if world > 1:
+        be.enable_timing(True)   # events around LOCAL / REMOTE (compute stream) and the exchange (comm stream)
     sync_all()
     t0 = time.perf_counter()
     system.step(args.dt, G, args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank = None
+    if world > 1:
+        mine = dict(be.pass_times(), rank=rank, device=local_rank, targets=int(system.layout.count), wall_s=elapsed)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+        be.enable_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -218,6 +297,13 @@ def main():
                 result["roofline"]["traffic_source"] = "profiles/r1c/pmc_force_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; raw, per launch)"
         except Exception:
             pass
+    if rank == 0 and world > 1:
+        # self-description of the N > 1 path (never executed on hardware before the driver's scaling run)
+        result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
+        result["exchange_transport"] = backend
+        result["exchange_check"] = exchange_check
+        result["per_rank"] = per_rank
+        result["exchange_hidden_behind_local_pass"] = all(bool(r["exchange_hidden"]) for r in per_rank)
     if world > 1:
         dist.barrier()
     if rank == 0:

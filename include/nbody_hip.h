@@ -188,7 +188,14 @@ enum { NBX_EXCHANGE_AUTO = 0, NBX_EXCHANGE_PEER_COPY = 1, NBX_EXCHANGE_RCCL = 2 
 int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, size_t n_total, int exchange);
 int nbx_node_destroy(nbx_node* node);
 int nbx_node_exchange_mode(const nbx_node* node, int* mode);
+/* With the RCCL exchange and more than one rank the first upload also runs nbx_node_verify_exchange once and
+ * fails (NBX_ERR_HIP, detail text) if the all-gather did not deliver every chunk. */
 int nbx_node_upload_bodies(nbx_node* node, const void* bodies, size_t body_stride_bytes);
+/* Self-check of the position exchange: every rank's copies of the chunks it does not own are overwritten with
+ * NaN, one exchange runs (RCCL all-gather or peer copies, as configured), and each copy is compared bit for bit
+ * with the owner's chunk on the host.  *mismatches = number of differing fp32 values over all ranks (0 = the
+ * exchange delivered every chunk everywhere).  Synchronises; leaves the buffers whole when it passes. */
+int nbx_node_verify_exchange(nbx_node* node, size_t* mismatches);
 int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
 /* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);

@@ -60,6 +60,7 @@ ABI = [
     ("nbx_node_destroy", _i, [_vp]),
     ("nbx_node_exchange_mode", _i, [_vp, _pi]),
     ("nbx_node_upload_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_node_verify_exchange", _i, [_vp, _c.POINTER(_sz)]),
     ("nbx_node_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
@@ -309,6 +310,12 @@ class Node:
         if dim != self.dim or b.shape[0] != self.n_total:
             raise ValueError("bodies shape does not match the node")
         self._ck(self.lib.nbx_node_upload_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_node_upload_bodies")
+
+    def verify_exchange(self) -> int:
+        """Poisoned-buffer self-check of the position exchange; returns the number of fp32 values that did not arrive."""
+        bad = ctypes.c_size_t(0)
+        self._ck(self.lib.nbx_node_verify_exchange(self.h, ctypes.byref(bad)), "nbx_node_verify_exchange")
+        return bad.value
 
     def set_tuning(self, source_splits: int = 0, variant: int = -1):
         self._ck(self.lib.nbx_node_set_tuning(self.h, source_splits, variant), "nbx_node_set_tuning")

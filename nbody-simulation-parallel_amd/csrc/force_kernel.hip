@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 
 // -------------------------------------------------------------------------------------------------
 // Close set (nbx_internal.h).  classify_close_kernel lists the shard's candidate targets (a coordinate
-// below kCloseCoord), refine_close_kernel keeps the ones that own a pair with 0 < r^2 < kBadR2 -- both
-// run once per position update.  close_set_path is executed by the EXTRA workgroups of a fast launch
+// below kCloseCoord; once per position update), classify_sources_kernel the candidate sources of the pass
+// being launched (over ALL of the pass's chunks, so pairs that straddle a shard boundary are seen), and
+// refine_close_kernel keeps the targets that own a pair with 0 < r^2 < kBadR2 against those sources.  close_set_path is executed by the EXTRA workgroups of a fast launch
 // (blockIdx.x < close_blocks, i.e. dispatched first in every slice row): workgroup (cx, y) takes blocks cx, cx + CX, ... of 256 listed targets
 // against source slice y with the exact compare-and-select guard, one target per lane, fp64 second
 // level, and writes close_acc[y][k][slot]; an empty list costs one scalar load.  The guarded work thus
@@ -349,20 +350,42 @@ __global__ __launch_bounds__(256) void classify_close_kernel(KArgs a) {
     }
 }
 
-// Candidates against candidates: keep those with a partner at 0 < r^2 < kBadR2 (see nbx_internal.h).
-// Fixed grid, grid-stride over (target block, source block) pairs of 256 candidates each, so the check of a
-// few thousand candidates spreads over the chip instead of running as a handful of long workgroups; a target
-// found bad by several workgroups is listed once (atomicExch on its flag).
+// Candidate SOURCES of the pass being launched: every real body of the pass's chunk list with a coordinate
+// below kCloseCoord, whichever shard owns it (grid = (pad/256, vchunks)).  Reads the exchange buffer as it
+// stands when the pass runs, so a REMOTE pass sees the other ranks' freshly gathered chunks.
+template <int D>
+__global__ __launch_bounds__(256) void classify_sources_kernel(KArgs a) {
+    const unsigned l = blockIdx.x * 256u + threadIdx.x;
+    int c = a.chunk_first + (int)blockIdx.y;
+    c += (c >= a.chunk_skip) ? 1 : 0;
+    const unsigned lo = (unsigned)c * a.shard_len;   // first global body of chunk c (host checks c * shard_len < 2^32)
+    const unsigned in_chunk = lo >= a.n_total ? 0u : ((a.n_total - lo < a.shard_len) ? a.n_total - lo : a.shard_len);
+    if (l >= in_chunk) return;                        // pad entries (massless, at the origin) are no sources
+    const float* __restrict__ sp = a.pos_all + (size_t)c * D * a.pad;
+    const float x = sp[l], y = sp[(size_t)a.pad + l], z = (D == 3) ? sp[2 * (size_t)a.pad + l] : 0.0f;
+    if (in_close_set<D>(x, y, z)) {
+        const unsigned slot = atomicAdd(&a.counters[2], 1u);
+        a.src_cand_pos[slot] = x;
+        a.src_cand_pos[(size_t)a.src_stride + slot] = y;
+        if (D == 3) a.src_cand_pos[2 * (size_t)a.src_stride + slot] = z;
+    }
+}
+
+// Candidate targets against the pass's candidate sources: keep the targets with a partner at 0 < r^2 < kBadR2
+// (see nbx_internal.h).  Fixed grid, grid-stride over (target block, source block) pairs of 256 candidates
+// each, so the check of a few thousand candidates spreads over the chip instead of running as a handful of
+// long workgroups; a target found bad by several workgroups is listed once (atomicExch on its flag).
 template <int D>
 __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
     __shared__ float tx[256], ty[256], tz[256];
     const unsigned tid = threadIdx.x;
-    const unsigned n = a.counters[0];
-    const unsigned nblk = (n + 255u) / 256u;
-    const bool keep_all = n > kRefineLimit;
-    const unsigned npairs = keep_all ? nblk : nblk * nblk;
-    for (unsigned p = blockIdx.x; p < npairs; p += gridDim.x) {
-        const unsigned tb = keep_all ? p : p / nblk, sb = keep_all ? 0u : p - tb * nblk;
+    const unsigned n = a.counters[0];    // candidate targets (own chunk)
+    const unsigned ns = a.counters[2];   // candidate sources (the pass's chunks)
+    const unsigned nblk = (n + 255u) / 256u, nsblk = (ns + 255u) / 256u;
+    const bool keep_all = n > kRefineLimit || (unsigned long long)n * ns > kRefinePairLimit;
+    const unsigned long long npairs = keep_all ? nblk : (unsigned long long)nblk * nsblk;
+    for (unsigned long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const unsigned tb = keep_all ? (unsigned)p : (unsigned)(p / nsblk), sb = keep_all ? 0u : (unsigned)(p - (unsigned long long)tb * nsblk);
         const unsigned slot = tb * 256u + tid;
         const bool valid = slot < n;
         const unsigned ls = valid ? slot : 0;
@@ -372,11 +395,11 @@ __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
             const unsigned j = sb * 256u + tid;
             __syncthreads();
             // out-of-range entries duplicate this lane's own position: r^2 = 0, never "bad"
-            tx[tid] = (j < n) ? a.cand_pos[j] : x;
-            ty[tid] = (j < n) ? a.cand_pos[(size_t)a.pad + j] : y;
-            tz[tid] = (D == 3 && j < n) ? a.cand_pos[2 * (size_t)a.pad + j] : z;
+            tx[tid] = (j < ns) ? a.src_cand_pos[j] : x;
+            ty[tid] = (j < ns) ? a.src_cand_pos[(size_t)a.src_stride + j] : y;
+            tz[tid] = (D == 3 && j < ns) ? a.src_cand_pos[2 * (size_t)a.src_stride + j] : z;
             __syncthreads();
-            const unsigned lim = (n - sb * 256u < 256u) ? n - sb * 256u : 256u;
+            const unsigned lim = (ns - sb * 256u < 256u) ? ns - sb * 256u : 256u;
             for (unsigned k = 0; k < lim; ++k) {
                 const float dx = tx[k] - x, dy = ty[k] - y;
                 float r2 = __builtin_fmaf(dy, dy, dx * dx);
@@ -634,6 +657,7 @@ const KernelVariant* NBX_CAT(variants_, NBX_FLAVOUR)(int* count) {
 CloseKernels close_kernels() {
     CloseKernels k;
     k.classify[0] = NBX_FLAVOUR::classify_close_kernel<2>; k.classify[1] = NBX_FLAVOUR::classify_close_kernel<3>;
+    k.classify_src[0] = NBX_FLAVOUR::classify_sources_kernel<2>; k.classify_src[1] = NBX_FLAVOUR::classify_sources_kernel<3>;
     k.refine[0] = NBX_FLAVOUR::refine_close_kernel<2>;     k.refine[1] = NBX_FLAVOUR::refine_close_kernel<3>;
     k.scatter[0] = NBX_FLAVOUR::scatter_close_kernel<2>;   k.scatter[1] = NBX_FLAVOUR::scatter_close_kernel<3>;
     k.potential[0] = NBX_FLAVOUR::potential_kernel<2>;     k.potential[1] = NBX_FLAVOUR::potential_kernel<3>;

@@ -4,6 +4,7 @@
 // whose extra workgroups evaluate the close set -> scatter), all asynchronous on the caller's stream with no host read-back.
 #include "nbx_internal.h"
 
+#include <climits>
 #include <cstring>
 #include <vector>
 
@@ -74,26 +75,47 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.bad_flag = L.bad_flag;
     a.counters = L.counters;
     a.close_acc = L.close_acc;
+    a.src_cand_pos = L.src_cand_pos;
+    a.src_stride = (unsigned)L.n_chunks * L.pad;
+    a.n_total = (unsigned)L.n_total;
+    a.shard_len = (unsigned)L.shard_len;
     // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
-    if (V.fast && (!L.cand_list || !L.cand_pos || !L.bad_list || !L.bad_flag || !L.counters || !L.close_acc)) return hipErrorInvalidValue;
+    if (V.fast && (!L.cand_list || !L.cand_pos || !L.bad_list || !L.bad_flag || !L.counters || !L.close_acc || !L.src_cand_pos)) return hipErrorInvalidValue;
+    if (V.fast && (L.n_chunks < 1 || L.n_total > ((size_t)1 << 31) || (size_t)L.n_chunks * L.pad > 0xffffffffull ||
+                   L.chunk_first < 0 || L.chunk_first + L.vchunks + (L.chunk_skip != INT_MAX ? 1 : 0) > L.n_chunks))
+        return hipErrorInvalidValue;
     if (V.max_tiles_per_slice > 0 && a.tiles_per_split > (unsigned)V.max_tiles_per_slice) return hipErrorInvalidValue;
 
     a.close_blocks = V.fast ? (unsigned)kCloseBlocksX : 0u;
     hipError_t e = hipSuccess;
     dim3 block(256, 1, 1);
     const int di = dim - 2;
-    if (V.fast && !(L.close_list_valid && *L.close_list_valid)) {  // (re)build the bad-target list for these positions
-        if ((e = hipMemsetAsync(L.counters, 0, 2 * sizeof(unsigned), stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(L.bad_flag, 0, (size_t)L.pad * sizeof(unsigned), stream)) != hipSuccess) return e;
-        if (L.count) {
-            hipLaunchKernelGGL(table().ck.classify[di], dim3((L.count + 255u) / 256u, 1, 1), block, 0, stream, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (V.fast) {
+        // Candidate targets: a property of the own chunk's positions (rebuilt after every position update).
+        if (!(L.tgt_cand_valid && *L.tgt_cand_valid)) {
+            if ((e = hipMemsetAsync(L.counters, 0, sizeof(unsigned), stream)) != hipSuccess) return e;
+            if (L.count) {
+                hipLaunchKernelGGL(table().ck.classify[di], dim3((L.count + 255u) / 256u, 1, 1), block, 0, stream, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            if (L.tgt_cand_valid) *L.tgt_cand_valid = 1;
+            if (L.bad_list_pass) *L.bad_list_pass = -1;
         }
-        if (L.close_list_valid) *L.close_list_valid = 1;
+        // Bad targets: a property of the own chunk AND of the pass's source chunks, which for a sharded ALL /
+        // REMOTE pass are rewritten behind the library's back by the exchange -- rebuilt for every such launch.
+        if (!(L.cacheable && L.bad_list_pass && *L.bad_list_pass == L.pass)) {
+            if ((e = hipMemsetAsync(L.counters + 1, 0, 2 * sizeof(unsigned), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(L.bad_flag, 0, (size_t)L.pad * sizeof(unsigned), stream)) != hipSuccess) return e;
+            if (L.count) {
+                hipLaunchKernelGGL(table().ck.classify_src[di], dim3(L.pad / 256u, (unsigned)L.vchunks, 1), block, 0, stream, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            if (L.bad_list_pass) *L.bad_list_pass = L.cacheable ? L.pass : -1;
+        }
     }
     dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;

@@ -113,8 +113,9 @@ int ensure_acc(nbx_ctx* c) {
             HIP_TRY(hipMalloc((void**)&c->cand_pos, (size_t)c->dim * c->pad * sizeof(float)));
             HIP_TRY(hipMalloc((void**)&c->bad_list, (size_t)c->pad * sizeof(unsigned)));
             HIP_TRY(hipMalloc((void**)&c->bad_flag, (size_t)c->pad * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->counters, 2 * sizeof(unsigned)));
-            c->close_list_valid = 0;
+            HIP_TRY(hipMalloc((void**)&c->counters, 4 * sizeof(unsigned)));
+            HIP_TRY(hipMalloc((void**)&c->src_cand_pos, (size_t)c->dim * c->n_shards * c->pad * sizeof(float)));
+            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
         }
         if (!(c->close_acc && c->close_splits_alloc >= c->splits)) {
             if (c->close_acc) { HIP_TRY(hipFree(c->close_acc)); c->close_acc = nullptr; }
@@ -236,6 +237,7 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->bad_flag) (void)hipFree(c->bad_flag);
     if (c->counters) (void)hipFree(c->counters);
     if (c->close_acc) (void)hipFree(c->close_acc);
+    if (c->src_cand_pos) (void)hipFree(c->src_cand_pos);
     if (c->phi) (void)hipFree(c->phi);
     if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);
     if (c->bulk0) (void)hipEventDestroy(c->bulk0);
@@ -319,7 +321,7 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
     c->uploaded = true;
     c->have_accel = false;
-    c->close_list_valid = 0;
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     return NBX_OK;
 }
 
@@ -362,8 +364,10 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
     L.cand_list = c->cand_list; L.cand_pos = c->cand_pos; L.bad_list = c->bad_list; L.bad_flag = c->bad_flag;
-    L.counters = c->counters; L.close_acc = c->close_acc;
-    L.close_list_valid = &c->close_list_valid;
+    L.counters = c->counters; L.close_acc = c->close_acc; L.src_cand_pos = c->src_cand_pos;
+    L.n_total = c->n_total; L.shard_len = c->shard_len; L.n_chunks = c->n_shards;
+    L.pass = which; L.cacheable = (c->n_shards == 1 || which == NBX_SRC_LOCAL) ? 1 : 0;
+    L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
     L.chunk_skip = INT_MAX; L.accumulate = 0;
     if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
@@ -393,7 +397,7 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
     k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
     HIP_TRY(launch_kick_drift(k, c->stream));
     c->have_accel = false;
-    c->close_list_valid = 0;  // positions moved
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;  // positions moved
     return NBX_OK;
 }
 
@@ -408,7 +412,7 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
     c->capturing = true;
-    c->close_list_valid = 0;
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     int rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
     if (!rc) rc = nbx_ctx_kick_drift(c, G, dt);
     c->capturing = false;
@@ -447,7 +451,7 @@ int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
             HIP_TRY(hipEventRecord(c->bulk1, c->stream));
             c->bulk_steps = nsteps;
             c->have_accel = false;
-            c->close_list_valid = 0;
+            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
         }
     }
     for (; s < nsteps; ++s) {

@@ -31,6 +31,7 @@ struct nbx_ctx {
     unsigned* counters = nullptr;
     float* close_acc = nullptr;
     int close_splits_alloc = 0;
+    float* src_cand_pos = nullptr;   // [dim][n_shards*pad] candidate sources of the pass being launched
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
     hipGraphExec_t step_exec = nullptr;
@@ -44,7 +45,8 @@ struct nbx_ctx {
     double bulk_ms_done = 0.0;   // already-resolved replay time not yet reported
     int bulk_steps_done = 0;
     bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
-    int close_list_valid = 0;   // the device list matches the positions in pos_all
+    int tgt_cand_valid = 0;     // the device's candidate-target list matches the own chunk's positions
+    int bad_list_pass = -1;     // NBX_SRC_* pass whose bad-target list is on the device (-1: none / stale)
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
     // boundary staging

@@ -32,16 +32,22 @@ static_assert((double)kR2SkipF >= 1e-10, "fp32 threshold must not round below th
 //     any |coordinate| < kCloseCoord (0.5 % of the reference's uniform bodies).  Conversely a non-candidate
 //     differs from every other body, in each coordinate where they differ, by >= 2^-10, so its non-zero r^2
 //     are >= 9.5e-7: never skipped by the reference and biased by < 1e-8 relative.
-//  2. refine_close_kernel checks the candidates against each other (all-pairs over the small list, the
-//     same fp32 r^2) and keeps those with a partner at 0 < r^2 < kBadR2 = 1e-6 (4x the X above) -- almost
-//     always none.  Above kRefineLimit candidates it keeps them all.
-// Bad targets are flagged (the fast kernel does not store them) and evaluated with the exact
-// compare-and-select guard by extra workgroups of the same launch (close_set_path), then scattered
-// into acc.  The result therefore has the reference's skip semantics for every pair.
+//  2. The same argument holds for the SOURCE member of such a pair, whichever chunk (shard) it lives in, so
+//     classify_sources_kernel lists the candidate sources of the pass being launched -- every real body of
+//     the pass's chunk list (ALL / LOCAL / REMOTE) with a coordinate below kCloseCoord, read from the exchange
+//     buffer as it stands when the pass runs (for REMOTE: after the all-gather) -- and refine_close_kernel
+//     checks the shard's candidate targets against that list (all-pairs over two small lists, the same fp32
+//     r^2) and keeps the targets with a partner at 0 < r^2 < kBadR2 = 1e-6 (4x the X above) -- almost
+//     always none.  Above kRefineLimit candidate targets (or kRefinePairLimit checks) it keeps them all.
+//     A pair that straddles a shard boundary is therefore found by the pass that evaluates it.
+// Bad targets of a pass are flagged (the fast kernel does not store them) and evaluated against that pass's
+// sources with the exact compare-and-select guard by extra workgroups of the same launch (close_set_path),
+// then scattered into acc.  The result therefore has the reference's skip semantics for every pair.
 constexpr float kTiny = 0x1p-47f;          // 7.1e-15
 constexpr float kCloseCoord = 16384.0f;
 constexpr float kBadR2 = 1.0e-6f;
-constexpr unsigned kRefineLimit = 131072;  // candidates beyond this are all treated as bad (O(n^2) check avoided)
+constexpr unsigned kRefineLimit = 131072;  // candidate targets beyond this are all treated as bad (O(n^2) check avoided)
+constexpr unsigned long long kRefinePairLimit = 1ull << 36;  // same for (candidate targets) x (candidate sources)
 // m / (kTiny^2) must stay finite in fp32 for a coincident source: masses above this force the exact path.
 constexpr double kFastMaxMass = 1.0e10;
 constexpr int kCloseBlocksX = 32;          // extra workgroups per source slice that a fast launch adds for bad targets
@@ -65,9 +71,16 @@ struct AccelLaunch {
     float* cand_pos;          // [dim][pad] their positions, compacted
     unsigned* bad_list;       // [pad] targets that own a pair with 0 < r^2 < kBadR2
     unsigned* bad_flag;  // [pad] 1 for listed targets
-    unsigned* counters;       // [0] = candidates, [1] = bad targets
+    unsigned* counters;       // [0] = candidate targets, [1] = bad targets, [2] = candidate sources
     float* close_acc;         // [splits][dim][pad]
-    int* close_list_valid;    // host flag owned by the context: lists match the current positions
+    float* src_cand_pos;      // [dim][n_shards*pad] positions of the pass's candidate sources, compacted
+    size_t n_total;           // real bodies over all chunks
+    size_t shard_len;         // real bodies per chunk (the last non-empty chunk may hold fewer)
+    int n_chunks;             // chunks in the exchange buffer (= n_shards)
+    int pass;                 // NBX_SRC_* selector of this launch (cache key of the bad-target list)
+    int cacheable;            // the pass's sources change only through this context (single shard, or LOCAL)
+    int* tgt_cand_valid;      // host flag owned by the context: cand_list matches the own chunk's positions
+    int* bad_list_pass;       // host flag owned by the context: pass whose bad list is current (-1: none)
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -92,6 +105,9 @@ struct KArgs {
     unsigned* __restrict__ bad_flag;
     unsigned* __restrict__ counters;
     float* __restrict__ close_acc;
+    float* __restrict__ src_cand_pos;
+    unsigned src_stride;       // floats between the coordinate planes of src_cand_pos (= n_chunks * pad)
+    unsigned n_total, shard_len;
 };
 
 struct KernelVariant {
@@ -105,7 +121,7 @@ struct KernelVariant {
 // force_kernel.hip, compiled once per code-generation flavour
 const KernelVariant* variants_slp(int* count);
 const KernelVariant* variants_scalar(int* count);
-struct CloseKernels { void (*classify[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); };  // [0]: D=2, [1]: D=3
+struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
 // force_launch.hip

@@ -15,6 +15,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -70,6 +71,7 @@ struct nbx_node {
     std::vector<Rank> ranks;
     Rccl rccl;
     bool uploaded = false;
+    bool exchange_verified = false;   // the RCCL exchange passed its poisoned-buffer self-check
 };
 
 namespace {
@@ -264,6 +266,59 @@ int nbx_node_upload_bodies(nbx_node* nd, const void* bodies, size_t stride_bytes
         k.chunk_floats = (size_t)nd->dim * k.ctx->pad;
     }
     nd->uploaded = true;
+    int rc = mark_ready(nd);
+    if (rc) return rc;
+    // First contact of the RCCL exchange with real hardware happens here, not silently inside a step: one
+    // poisoned all-gather must restore every chunk on every rank, or the upload fails loudly.
+    if (nd->exchange == NBX_EXCHANGE_RCCL && nd->n_ranks > 1 && !nd->exchange_verified) {
+        size_t bad = 0;
+        rc = nbx_node_verify_exchange(nd, &bad);
+        if (rc) return rc;
+        if (bad) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "RCCL all-gather self-check failed: %zu fp32 position values did not arrive", bad);
+            return fail(NBX_ERR_HIP, buf);
+        }
+        nd->exchange_verified = true;
+    }
+    return NBX_OK;
+}
+
+int nbx_node_verify_exchange(nbx_node* nd, size_t* mismatches) {
+    if (!nd || !mismatches) return fail(NBX_ERR_INVALID, "null argument");
+    if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    *mismatches = 0;
+    const int R = nd->n_ranks;
+    if (R == 1) return NBX_OK;
+    // poison every chunk a rank does not own (0xFF bytes = NaN), ordered before the exchange through `ready`
+    for (int r = 0; r < R; ++r) {
+        Rank& k = nd->ranks[r];
+        NBX_HIP_TRY(hipSetDevice(k.device));
+        for (int q = 0; q < R; ++q)
+            if (q != r) NBX_HIP_TRY(hipMemsetAsync(k.pos_all + (size_t)q * k.chunk_floats, 0xFF, k.chunk_floats * sizeof(float), k.ctx->stream));
+    }
+    int rc = mark_ready(nd);
+    if (!rc) rc = start_exchange(nd);
+    if (!rc) rc = finish_exchange(nd);
+    if (!rc) rc = nbx_node_synchronize(nd);
+    if (rc) return rc;
+    // every rank's copy of chunk q must equal, bit for bit, the copy held by its owner (never poisoned)
+    const size_t chunk = nd->ranks[0].chunk_floats;
+    std::vector<uint32_t> owner(chunk), copy(chunk);
+    size_t bad = 0;
+    for (int q = 0; q < R; ++q) {
+        Rank& o = nd->ranks[q];
+        NBX_HIP_TRY(hipSetDevice(o.device));
+        NBX_HIP_TRY(hipMemcpy(owner.data(), o.pos_all + (size_t)q * chunk, chunk * sizeof(float), hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r) {
+            if (r == q) continue;
+            Rank& k = nd->ranks[r];
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            NBX_HIP_TRY(hipMemcpy(copy.data(), k.pos_all + (size_t)q * chunk, chunk * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < chunk; ++i) bad += owner[i] != copy[i];
+        }
+    }
+    *mismatches = bad;
     return mark_ready(nd);
 }
 

@@ -49,13 +49,53 @@ class HipShardBackend:
         self.ctx.set_tuning(source_splits, variant)
         torch.cuda.synchronize(self.device)  # zero fills done before the library's stream writes
         self.ctx.upload(bodies)
+        self._timing = False
+        self._marks = []       # per step: dict of torch events (see enable_timing)
+        self._cur = None
+
+    # -- pass timing (bench.py --gpus N): events on the streams the work really runs on --
+    def enable_timing(self, on: bool = True):
+        """Record, per force evaluation, events around the LOCAL pass and the REMOTE pass (compute stream) and
+        around the position exchange (comm stream), so that a first run on a multi-GPU node describes itself:
+        how long each pass took and whether the collective was hidden behind the LOCAL pass."""
+        self._timing = on
+        self._marks = []
+        self._cur = None
+
+    def _mark(self, key, stream):
+        if self._timing and self._cur is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            self._cur[key] = e
+
+    def pass_times(self):
+        """Means over the recorded force evaluations, in ms; exchange_hidden = every exchange had finished
+        before the LOCAL pass of the same step did."""
+        self.synchronize()
+        loc, rem, exc, hidden = [], [], [], []
+        for m in self._marks:
+            if "l0" in m and "l1" in m:
+                loc.append(m["l0"].elapsed_time(m["l1"]))
+            if "r0" in m and "r1" in m:
+                rem.append(m["r0"].elapsed_time(m["r1"]))
+            if "x0" in m and "x1" in m:
+                exc.append(m["x0"].elapsed_time(m["x1"]))
+                if "l0" in m and "l1" in m:
+                    hidden.append(m["l0"].elapsed_time(m["x1"]) <= m["l0"].elapsed_time(m["l1"]))
+        mean = lambda v: float(sum(v) / len(v)) if v else None
+        return {"local_ms": mean(loc), "remote_ms": mean(rem), "exchange_ms": mean(exc), "evaluations": len(self._marks),
+                "exchange_hidden": bool(hidden) and all(hidden), "exchange_hidden_count": int(sum(hidden))}
 
     # -- the five operations the orchestrator needs --
     def accel_local(self):
+        self._mark("l0", self.compute_stream)
         self.ctx.compute_accel(capi.SRC_LOCAL)
+        self._mark("l1", self.compute_stream)
 
     def accel_remote(self):
+        self._mark("r0", self.compute_stream)
         self.ctx.compute_accel(capi.SRC_REMOTE)
+        self._mark("r1", self.compute_stream)
 
     def kick_drift(self, G: float, dt: float):
         self.ctx.kick_drift(dt, G)
@@ -63,9 +103,13 @@ class HipShardBackend:
     def start_exchange(self, group):
         """Launch the position all-gather on the comm stream, ordered after everything already
         queued on the compute stream (the previous drift), and return the work handle."""
+        if self._timing:
+            self._cur = {}
+            self._marks.append(self._cur)
         if self.layout.n_shards == 1:
             return None
         self.comm_stream.wait_stream(self.compute_stream)
+        self._mark("x0", self.comm_stream)
         if dist.get_backend(group) != "nccl":
             # Rehearsal transport (gloo has no device collectives): stage the own chunk through host
             # memory.  Same buffers, same ordering; only the wire differs.  Not used on a multi-GPU node.
@@ -88,7 +132,24 @@ class HipShardBackend:
         if work != "staged":
             with torch.cuda.stream(self.comm_stream):
                 work.wait()
+        self._mark("x1", self.comm_stream)
         self.compute_stream.wait_stream(self.comm_stream)
+
+    # -- exchange self-check (first contact with a multi-GPU node) --
+    def poison_remote_chunks(self):
+        """Overwrite every chunk this rank does not own with NaN, so that only a working exchange can
+        restore them.  Ordered on the compute stream (the exchange waits for it)."""
+        with torch.cuda.stream(self.compute_stream):
+            for g in range(self.layout.n_shards):
+                if g != self.layout.shard:
+                    self.pos_all[g].fill_(float("nan"))
+
+    def remote_chunk_mismatches(self, bodies: np.ndarray) -> int:
+        """Number of fp32 position values in the other ranks' chunks that differ from the fp32-rounded
+        positions of `bodies` (host compare).  Only meaningful while the bodies have not moved."""
+        self.synchronize()
+        host = self.pos_all.cpu().numpy()
+        return _count_chunk_mismatches(host, bodies, self.layout)
 
     # -- results --
     def forces(self, G: float) -> np.ndarray:
@@ -109,6 +170,18 @@ class HipShardBackend:
 
     def close(self):
         self.ctx.close()
+
+
+def _count_chunk_mismatches(pos_all_host: np.ndarray, bodies: np.ndarray, layout: ShardLayout) -> int:
+    bad = 0
+    for g in range(layout.n_shards):
+        if g == layout.shard:
+            continue
+        lo, hi = layout.bounds(g)
+        want = np.ascontiguousarray(bodies[lo:hi, :layout.dim].T.astype(np.float32))
+        got = pos_all_host[g, :, : hi - lo]
+        bad += int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    return bad
 
 
 class ShardedNBody:
@@ -134,6 +207,25 @@ class ShardedNBody:
         self.be.finish_exchange(work)
         if self.layout.n_shards > 1:
             self.be.accel_remote()
+
+    def verify_exchange(self, bodies: np.ndarray) -> int:
+        """Self-check of the position exchange, to be called BEFORE the first step (while the device positions
+        still equal the uploaded ones): every rank poisons the chunks it does not own, the exchange runs once,
+        and each remote chunk is compared on the host with the fp32-rounded positions of `bodies` (identical on
+        every rank).  Returns the number of mismatching values summed over all ranks: 0 = the collective
+        delivered every chunk to every rank.  A transport that does nothing, or gathers into the wrong
+        offsets, cannot pass."""
+        if self.layout.n_shards == 1:
+            return 0
+        self.be.poison_remote_chunks()
+        work = self.be.start_exchange(self.group)
+        self.be.finish_exchange(work)
+        bad = self.be.remote_chunk_mismatches(bodies)
+        t = torch.tensor([bad], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
 
     def step(self, dt: float, G: float = capi.REFERENCE_G, nsteps: int = 1):
         for _ in range(nsteps):

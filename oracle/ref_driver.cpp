@@ -9,6 +9,7 @@
 // vectors under tests/golden/, (3) optionally serve as bench.py's cpu_baseline kind "reference".
 #include "methods.h"   // /root/reference/nbody-sim-new/methods.h (via -I)
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <random>
@@ -35,10 +36,36 @@ int forces(int variant, const double* raw, size_t n, double* out) {
         case 0: f = brute_force_seq_n_body<D>(b); break;
         case 1: f = brute_force_omp_n_body_1<D>(b); break;
         case 2: f = brute_force_omp_n_body_2<D>(b); break;
+        case 3:
+        case 4: {  // the ParlayLib twins (methods.cpp:139-186, :189-224) take and return parlay::sequence
+            parlay::sequence<Body<D>> pb(b.begin(), b.end());   // as the harness does, main.cpp:95
+            const parlay::sequence<Vector<D>> pf = variant == 3 ? brute_force_parlay_n_body_1<D>(pb) : brute_force_parlay_n_body_2<D>(pb);
+            f.assign(pf.begin(), pf.end());
+            break;
+        }
         default: return -1;
     }
     unwrap<D>(f, out);
     return 0;
+}
+// Same call, timed around the solver only (the wrap/unwrap copies above are the shim's, not the reference's).
+template <int D>
+int timed(int variant, const double* raw, size_t n, double* seconds) {
+    auto b = wrap<D>(raw, n);
+    parlay::sequence<Body<D>> pb;
+    if (variant >= 3) pb = parlay::sequence<Body<D>>(b.begin(), b.end());
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t got = 0;
+    switch (variant) {
+        case 0: got = brute_force_seq_n_body<D>(b).size(); break;
+        case 1: got = brute_force_omp_n_body_1<D>(b).size(); break;
+        case 2: got = brute_force_omp_n_body_2<D>(b).size(); break;
+        case 3: got = brute_force_parlay_n_body_1<D>(pb).size(); break;
+        case 4: got = brute_force_parlay_n_body_2<D>(pb).size(); break;
+        default: return -1;
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return got == n ? 0 : -2;
 }
 }  // namespace
 
@@ -47,12 +74,22 @@ extern "C" {
 int ref_sizeof_body(int D) { return D == 2 ? (int)sizeof(Body<2>) : (int)sizeof(Body<3>); }
 double ref_G() { return G; }
 
-// variant: 0 = brute_force_seq_n_body, 1 = brute_force_omp_n_body_1, 2 = brute_force_omp_n_body_2
+// variant: 0 = brute_force_seq_n_body, 1 = brute_force_omp_n_body_1, 2 = brute_force_omp_n_body_2,
+//          3 = brute_force_parlay_n_body_1, 4 = brute_force_parlay_n_body_2 (thread count: PARLAY_NUM_THREADS)
 int ref_brute_force(int variant, const double* bodies, size_t n, int D, double* out) {
     if (D == 2) return forces<2>(variant, bodies, n, out);
     if (D == 3) return forces<3>(variant, bodies, n, out);
     return -1;
 }
+
+// Wall time of the reference solver call alone (what the reference's safely_execute times, utils.h:87-104).
+int ref_time_brute_force(int variant, const double* bodies, size_t n, int D, double* seconds) {
+    if (D == 2) return timed<2>(variant, bodies, n, seconds);
+    if (D == 3) return timed<3>(variant, bodies, n, seconds);
+    return -1;
+}
+
+int ref_parlay_num_workers() { return (int)parlay::num_workers(); }
 
 int ref_update_body_velocities(double* bodies, const double* f, size_t n, int D, double dt) {
     if (D == 2) {

@@ -63,6 +63,15 @@ class CpuShardDouble:
         if work is not None:
             work.wait()
 
+    def poison_remote_chunks(self):
+        for g in range(self.layout.n_shards):
+            if g != self.layout.shard:
+                self.pos_all[g].fill_(float("nan"))
+
+    def remote_chunk_mismatches(self, bodies):
+        from nbody_amd import package
+        return package.dist._count_chunk_mismatches(self.pos_all.numpy(), bodies, self.layout)
+
     def forces(self, G):
         return -((G * self.m)[:, None] * self.acc)
 

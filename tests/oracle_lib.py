@@ -150,6 +150,16 @@ class Reference:
         assert self.lib.ref_brute_force(variant, _p(bodies), _sz(bodies.shape[0]), d, _p(f)) == 0
         return f
 
+    def time_brute_force(self, variant, bodies):
+        """Seconds spent inside the reference solver itself (0 seq, 1 omp_1, 2 omp_2, 3 parlay_1, 4 parlay_2)."""
+        d = (bodies.shape[1] - 1) // 2
+        t = ctypes.c_double(0.0)
+        assert self.lib.ref_time_brute_force(variant, _p(bodies), _sz(bodies.shape[0]), d, ctypes.byref(t)) == 0
+        return t.value
+
+    def parlay_num_workers(self):
+        return self.lib.ref_parlay_num_workers()
+
     def update_body_velocities(self, bodies, forces, dt):
         d = (bodies.shape[1] - 1) // 2
         assert self.lib.ref_update_body_velocities(_p(bodies), _p(forces), _sz(bodies.shape[0]), d, ctypes.c_double(dt)) == 0
@@ -171,21 +181,28 @@ def have_reference() -> bool:
 # The device sums N fp32 pair terms; the oracle is the reference's fp64 sequential path fed the
 # same fp32-rounded inputs.  For body i let F_i be the oracle force, S_i = sum_j |f_ij| the sum of
 # pair-force magnitudes and kappa_i = S_i/|F_i| the condition number of the (cancelling) sum.
-#   (T1) |dF_i| <= TOL_BACKWARD * S_i            for EVERY body          (backward-stable sum)
-#   (T2) |dF_i| <= TOL_REL * |F_i|               for every body with kappa_i <= KAPPA_WELL
-# (T2) is BASELINE.json's "accelerations within 1e-5 relative"; bodies whose pair forces cancel to
-# less than 1/16 of their magnitude sum (about 2 % of uniform-random bodies; kappa reaches ~250 at
-# N=4096) cannot meet a plain relative bound in fp32 by construction -- they are held to (T1).
+#   (T1) |dF_i| <= TOL_BACKWARD * S_i            for EVERY body, every input  (backward-stable sum)
+#   (T2) |dF_i| <= TOL_REL * |F_i|               for every body with kappa_i <= KAPPA_WELL, every input
+#   (T3) |dF_i| <= TOL_REL * |F_i|               for EVERY body on BASELINE's uniform-random 3D configs
+# (T3) is BASELINE.json's "accelerations within 1e-5 relative", asserted unconditionally where the north star
+# states it (assert_plain_relative).  Measured (profiles/r2/accuracy_survey.jsonl): N=65,536 3D, all 65,536
+# bodies: max 6.3e-6 (kappa up to 179); N=2^20 3D, 2,048 rows: max 2.8e-6.  On OTHER inputs (2D, clustered,
+# adversarial) a plain relative bound is not attainable in fp32: each pair term carries ~4u rms relative
+# error, so a body whose two nearest neighbours pull in opposite directions with kappa = 460 (seen at
+# N=65,536 2D) is off by ~1e-4 however the sum is organised (70 of 65,536 2D bodies exceed 1e-5, all with
+# kappa >= 11) -- those inputs are held to (T1) + (T2).
 # (T1)'s constant: with unit roundoff u = 2^-24 = 6e-8, ONE fp32 pair term m*d/(r^2)^2 carries at most
 # 18u (d: 1u; r^2: 5u, entering squared: 10u; v_rcp_f32 1 ulp = 2u, squared: 4u; three products: 3u),
 # and the term then rides through ~512 fp32 additions (256-term tile sum + up to 256 tile flushes;
 # a term added early into a sum it dominates sees every later rounding): rms sqrt(512)*u/sqrt(3) = 13u,
-# 3.5 sigma = 46u.  18u + 46u = 64u = 3.8e-6.  Measured maxima: 1.0-1.7e-6 on uniform bodies, 2.5-2.6e-6
-# when one close or very massive neighbour dominates a sum (reproduced by a numpy fp32 emulation with
-# a correctly rounded reciprocal, so it is the arithmetic, not the kernel).
+# 3.5 sigma = 46u.  18u + 46u = 64u = 3.8e-6.  Measured maxima: 1.3-2.1e-6 on uniform bodies (full N=65,536),
+# 2.5-2.6e-6 when one close or very massive neighbour dominates a sum (reproduced by a numpy fp32 emulation
+# with a correctly rounded reciprocal, so it is the arithmetic, not the kernel).
+# KAPPA_WELL = 4: (T2) then follows from the measured backward maxima (2.1e-6 * 4 < 1e-5) instead of relying
+# on the worst backward error never meeting a moderately ill-conditioned body.
 TOL_REL = 1.0e-5
 TOL_BACKWARD = 4.0e-6
-KAPPA_WELL = 16.0
+KAPPA_WELL = 4.0
 
 
 def force_errors(forces, ref_forces, magnitude_sums):
@@ -210,6 +227,16 @@ def assert_force_parity(forces, ref_forces, magnitude_sums, what=""):
     assert e["max_backward"] <= TOL_BACKWARD, f"{what}: backward error {e['max_backward']:.3e} > {TOL_BACKWARD} ({e})"
     assert e["max_rel_well"] <= TOL_REL, f"{what}: relative error {e['max_rel_well']:.3e} > {TOL_REL} on well-conditioned bodies ({e})"
     return e
+
+
+def assert_plain_relative(forces, ref_forces, what="", tol=TOL_REL):
+    """(T3): BASELINE's unconditional bound, max over ALL bodies of |dF_i|/|F_i| (= |da_i|/|a_i|) <= 1e-5."""
+    dF = np.sqrt(((forces - ref_forces) ** 2).sum(axis=1))
+    nF = np.sqrt((ref_forces ** 2).sum(axis=1))
+    assert (nF > 0).all(), f"{what}: a reference force vanishes exactly"
+    worst = float((dF / nF).max())
+    assert worst <= tol, f"{what}: max relative acceleration error {worst:.3e} > {tol} over all {forces.shape[0]} bodies"
+    return worst
 
 
 def accel_errors(forces, ref_forces, masses, G):

@@ -37,6 +37,15 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         layout = pkg.sharding.ShardLayout(n_total=n, n_shards=world, shard=rank, dim=dim)
         be = CpuShardDouble(bodies, layout)
         sysm = pkg.dist.ShardedNBody(be, layout)
+        # exchange self-check (what bench.py --gpus N runs first on a multi-GPU node): clean pass, then a
+        # deliberately broken transport must be caught
+        clean = sysm.verify_exchange(bodies)
+        real_start = be.start_exchange
+        be.start_exchange = lambda group: None           # a collective that delivers nothing
+        broken = sysm.verify_exchange(bodies)
+        be.start_exchange = real_start
+        assert sysm.verify_exchange(bodies) == 0           # and the buffers are whole again
+        del be.calls[:]
         sysm.compute_forces()
         f0 = sysm.forces(o.G * gscale)
         sysm.step(dt, o.G * gscale, steps)
@@ -45,7 +54,7 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         ke, pe = sysm.energy(o.G * gscale)
         lo, hi = layout.bounds()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi, calls=np.array(be.calls[:ncalls]),
-                 energy=np.array([ke, pe]))
+                 energy=np.array([ke, pe]), verify=np.array([clean, broken]))
     finally:
         dist.destroy_process_group()
 
@@ -72,6 +81,8 @@ def test_sharded_steps_match_oracle(tmp_path, oracle, world, n, dim):
         if hi > lo:
             assert np.abs(z["f0"] - ref_f0[lo:hi]).max() <= 1e-9 * max(scale, 1e-300)
         finals.append(z["final"])
+        others = n - (hi - lo)
+        assert z["verify"][0] == 0 and (z["verify"][1] == dim * (world * n - n) if world > 1 else z["verify"][1] == 0), z["verify"]
         calls = list(z["calls"])
         per = ["exchange", "local", "remote"] if world > 1 else ["exchange", "local"]
         assert calls == per + (per + ["kick_drift"]) * steps, "exchange must precede the local pass every step"

@@ -1,13 +1,16 @@
-"""GPU: BASELINE.json's full sizes.  The oracle cannot evaluate N^2 pairs at N = 2^20 in test time,
-so parity is by sampled target rows (each row of the reference's omp_2 form is independent,
-methods.cpp:110-133) plus size-independent properties of the force law:
+"""GPU: BASELINE.json's full sizes, by SURVEY 8(d)'s accuracy protocol: the FULL force array at N = 65,536
+against the oracle's brute_force_omp_2 (4.3e9 pair evaluations, ~2-3 s on the box's host cores), and >= 1,024
+sampled target rows at N >= 2^20, where the oracle cannot evaluate N^2 pairs in test time (each row of the
+reference's omp_2 form is independent, methods.cpp:110-133).  On these uniform-random 3D configs the north
+star's bound is asserted UNCONDITIONALLY: max over all compared bodies of |da|/|a| <= 1e-5 (T3 in
+oracle_lib.py), beside the backward bound (T1).  Plus size-independent properties of the force law:
   * Newton's third law: sum_i F_i = 0  (the reference's seq path applies +f/-f per pair);
   * permutation equivariance: shuffling the bodies shuffles the forces;
   * sharding invariance: G virtual ranks reproduce the single-shard result."""
 import numpy as np
 import pytest
 
-from oracle_lib import TOL_BACKWARD, assert_force_parity
+from oracle_lib import TOL_BACKWARD, assert_force_parity, assert_plain_relative
 
 pytestmark = pytest.mark.gpu
 
@@ -23,13 +26,21 @@ def _sampled_parity(nbx, oracle, n, dim, nrows, seed):
     ref = oracle.force_rows_omp_2(b, rows)
     S = oracle.force_magnitude_sums(b, rows)
     e = assert_force_parity(f[rows], ref, S, f"sampled rows N={n}")
+    e["max_rel_plain"] = assert_plain_relative(f[rows], ref, f"sampled rows N={n} D={dim}")
+    e["rows"] = int(rows.size)
     return b, f, ms, e
 
 
 def test_config2_n65536(nbx, oracle):
-    """BASELINE config 2: N=65,536 3D, LDS tile 256."""
-    b, f, ms, e = _sampled_parity(nbx, oracle, 65536, 3, 512, 2)
-    m = b[:, -1]
+    """BASELINE config 2: N=65,536 3D, LDS tile 256 -- every one of the 65,536 forces against the oracle."""
+    n = 65536
+    b = oracle.round_inputs_to_f32(oracle.generate(2, n, 3))
+    f = nbx.brute_force_hip_n_body(b, oracle.G)
+    ref = oracle.brute_force_omp_2(b)            # = brute_force_seq up to fp64 re-association (<= 1e-9, SURVEY 8c)
+    e = assert_force_parity(f, ref, oracle.force_magnitude_sums(b), "full N=65,536")
+    worst = assert_plain_relative(f, ref, "full N=65,536 3D")
+    print(f"\nN=65,536 full: max |da|/|a| = {worst:.3e} over all bodies, {e}")
+    assert oracle.compute_accuracy(f, ref) == 100.0          # the reference's own 1 % metric (utils.h:170-219)
     total = np.abs(f).sum(axis=0)
     assert (np.abs(f.sum(axis=0)) <= 1e-5 * total).all(), "Newton's third law"
     # permutation equivariance
@@ -56,7 +67,8 @@ def test_config2_leapfrog_100_steps(nbx, oracle):
 def test_config3_n1048576_sampled_rows_and_properties(nbx, oracle):
     """BASELINE config 3: N = 2^20, one force evaluation, sampled rows vs the oracle."""
     n = 1 << 20
-    b, f, ms, e = _sampled_parity(nbx, oracle, n, 3, 96, 3)
+    b, f, ms, e = _sampled_parity(nbx, oracle, n, 3, 2048, 3)
+    assert e["rows"] >= 1024
     total = np.abs(f).sum(axis=0)
     assert (np.abs(f.sum(axis=0)) <= 1e-5 * total).all(), "Newton's third law"
     rate = n * n / (ms * 1e-3)

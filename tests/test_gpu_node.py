@@ -21,6 +21,7 @@ def test_virtual_ranks_forces_and_steps(nbx, oracle, ranks, n, dim):
     with nbx.Node(n, dim, [0] * ranks) as node:
         assert node.exchange == nbx.EXCHANGE_PEER_COPY        # AUTO falls back: the ranks share a device
         node.upload(b)
+        assert node.verify_exchange() == 0                    # poisoned-buffer self-check of the exchange (peer copies here)
         f = node.forces(oracle.G)
         assert f.shape == (n, dim)
         assert_force_parity(f, ref, S, f"node, {ranks} virtual ranks")

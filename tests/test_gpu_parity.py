@@ -1,7 +1,8 @@
 """GPU: the HIP path (through the C ABI) against the CPU oracle = the reference's sequential
 brute-force path on the same fp32-representable inputs.  Tolerance: oracle_lib.TOL_* (stated in
-DESIGN.md): |dF| <= 1e-6 * sum_j|f_ij| for every body and |dF| <= 1e-5*|F| for every body whose
-pair forces do not cancel below 1/32 of their magnitude sum."""
+DESIGN.md): (T1) |dF| <= 4e-6 * sum_j|f_ij| for every body and (T2) |dF| <= 1e-5*|F| for every body whose
+pair forces do not cancel below 1/4 of their magnitude sum; the unconditional 1e-5 bound (T3) is asserted on
+BASELINE's uniform 3D configs in test_gpu_fullsize.py."""
 import numpy as np
 import pytest
 

@@ -14,6 +14,11 @@ def test_live_reference(oracle, reference, dim, n, seed):
     assert np.array_equal(oracle.brute_force_omp_2(b), reference.brute_force(2, b))
     f1, r1 = oracle.brute_force_omp_1(b), reference.brute_force(1, b)
     assert np.array_equal(f1, r1)  # same thread count in one process => same partition => same bits
+    # the ParlayLib twins (methods.cpp:139-224): parlay_2 sums each row in source order like omp_2 => same bits;
+    # parlay_1 privatises per worker (scheduling-dependent partition) => re-association noise only
+    assert np.array_equal(reference.brute_force(4, b), reference.brute_force(2, b))
+    p1 = reference.brute_force(3, b)
+    assert np.allclose(p1, r1, rtol=0, atol=1e-9 * np.abs(r1).max())
     f = oracle.brute_force_seq(b)
     a, c = b.copy(), b.copy()
     oracle.update_body_velocities(a, f, 123.5)

@@ -1,0 +1,48 @@
+"""Accuracy evidence of SURVEY 8(d): device accelerations vs the oracle (reference arithmetic, fp64, fp32-rounded
+inputs) on BASELINE's uniform configs -- FULL N at N = 65,536 (oracle brute_force_omp_2) and >= 1,024 sampled
+target rows at N = 2^20 -- with the distribution of per-body relative errors, the condition numbers of the
+offenders and the max-abs acceleration error.  Test infrastructure (uses oracle/); prints JSON lines."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+import numpy as np
+import nbody_amd as nbx
+from oracle_lib import Oracle, force_errors
+
+o = Oracle()
+cases = [(65536, 3, None, 2), (65536, 2, None, 2), (1 << 20, 3, 2048, 3), (1 << 20, 2, 1024, 3)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if str(c[0]) in sys.argv[1:]]
+for n, dim, nrows, seed in cases:
+    b = o.round_inputs_to_f32(o.generate(seed, n, dim))
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.compute_accel()
+        f = c.forces(o.G)
+        name = c.effective_tuning()[0]
+    t0 = time.perf_counter()
+    if nrows is None:
+        rows = np.arange(n)
+        ref = o.brute_force_omp_2(b)
+        S = o.force_magnitude_sums(b)
+    else:
+        rows = np.unique(np.random.default_rng(seed).integers(0, n, nrows))
+        ref = o.force_rows_omp_2(b, rows)
+        S = o.force_magnitude_sums(b, rows)
+    t_or = time.perf_counter() - t0
+    fr = f[rows]
+    e = force_errors(fr, ref, S)
+    m = b[rows, -1][:, None]
+    dF = np.sqrt(((fr - ref) ** 2).sum(1)); nF = np.sqrt((ref ** 2).sum(1))
+    rel = dF / nF
+    kappa = S / nF
+    over = rel > 1e-5
+    e.pop("n", None)
+    out = dict(n=n, dim=dim, rows=int(rows.size), variant=name, oracle_s=round(t_or, 2), **e,
+               max_abs_accel_err=float(np.abs((fr - ref) / m).max()), max_abs_accel=float(np.abs(ref / m).max()),
+               n_over_1e5=int(over.sum()), kappa_of_offenders_min=float(kappa[over].min()) if over.any() else None,
+               rel_percentiles={str(p): float(np.percentile(rel, p)) for p in (50, 90, 99, 99.9, 100)},
+               kappa_percentiles={str(p): float(np.percentile(kappa, p)) for p in (50, 90, 99, 99.9, 100)},
+               backward_percentiles={str(p): float(np.percentile(dF / S, p)) for p in (50, 99, 100)})
+    print(json.dumps(out), flush=True)
