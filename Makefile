@@ -17,19 +17,16 @@ all: lib oracle nbody_sim
 
 lib: $(LIB)
 
-OBJS := $(CSRC)/force_kernel_slp.o $(CSRC)/force_kernel_scalar.o $(CSRC)/force_launch.o \
+OBJS := $(CSRC)/force_kernel.o $(CSRC)/force_launch.o \
         $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o
 # name of the force-kernel variant used when the caller does not pick one
-DEFAULT_VARIANT ?= fastpks_t8_w3_u4_scalar
+DEFAULT_VARIANT ?= fastpk_t8_w3_u4
 # exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
-DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8_scalar
+DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8
 
-# the force kernel is built in two code-generation flavours (see force_kernel.hip)
-$(CSRC)/force_kernel_slp.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
-	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=slp -c $< -o $@
-
-$(CSRC)/force_kernel_scalar.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
-	$(HIPCC) $(HIPFLAGS) -DNBX_FLAVOUR=scalar -DNBX_EMIT_CLOSE_KERNELS -fno-slp-vectorize -c $< -o $@
+# -fno-slp-vectorize: the packed arithmetic is written by hand on float2 values (see force_kernel.hip)
+$(CSRC)/force_kernel.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h Makefile
 	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -DNBX_DEFAULT_EXACT_VARIANT='"$(DEFAULT_EXACT_VARIANT)"' -c $< -o $@

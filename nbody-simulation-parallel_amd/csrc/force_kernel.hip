@@ -10,8 +10,7 @@
 //   * one lane = TPL targets held in VGPRs; a 256-lane workgroup = 4 wave64 = 256*TPL targets;
 //   * sources stream through LDS in tiles of 256 bodies {x,y,z,m} (one ds_write_b128 per lane per
 //     tile, double-buffered: one s_barrier per tile); every lane reads the same LDS address, so a
-//     single ds_read_b128 broadcast feeds 64*TPL pair interactions -- or (SMEM variants) sources
-//     arrive through the scalar cache as SGPR operands and cost no vector or LDS instruction;
+//     single ds_read_b128 broadcast feeds 64*TPL pair interactions;
 //   * exact kernels: 14 VALU per pair (v_sub x3, v_mul, v_fma x2, v_cmp+v_cndmask, v_rcp, v_mul x2,
 //     v_fma x3).  Fast kernels: targets are held as float2 pairs and the arithmetic is written on
 //     2-vectors (v_pk_add/mul/fma_f32: 12-25 % cheaper per element than the scalar forms on gfx950,
@@ -28,22 +27,13 @@
 #include <climits>
 #include <cmath>
 
-// This file is compiled twice (Makefile): NBX_FLAVOUR=slp with hipcc's defaults (the SLP vectoriser
-// pairs the TPL>=2 arithmetic of the scalar-source kernels into v_pk_*_f32) and NBX_FLAVOUR=scalar
-// with -fno-slp-vectorize.  Both flavours sit in one library so they can be A/B-timed in one process.
-#ifndef NBX_FLAVOUR
-#define NBX_FLAVOUR slp
-#endif
-#define NBX_STR2(x) #x
-#define NBX_STR(x) NBX_STR2(x)
-#define NBX_CAT2(a, b) a##b
-#define NBX_CAT(a, b) NBX_CAT2(a, b)
-
+// Compiled with -fno-slp-vectorize (Makefile): the packed arithmetic is written out on float2 values; letting
+// hipcc's SLP vectoriser re-pair the scalar kernels' arithmetic on top of that was measured slower in round 1
+// (profiles/r1b/variants_*.txt).
 namespace nbx {
-namespace NBX_FLAVOUR {
 namespace {
 
-enum Guard { GUARD_EXACT = 0, GUARD_TINY = 2 };
+enum Guard { GUARD_EXACT = 0, GUARD_TINY = 2 };  // GUARD_TINY: scalar form of the fast kernels' arithmetic (unused by the table)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -71,36 +61,15 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
     if (D == 3) az = __builtin_fmaf(s, dz, az);
 }
 
-// The same for a PAIR of targets held in the two halves of 64-bit registers.
-template <int D, int GUARD>
-__device__ __forceinline__ void interact2(float sx, float sy, float sz, float sm, f2 ix, f2 iy, f2 iz,
-                                          f2& ax, f2& ay, f2& az) {
-    const f2 dx = f2{sx, sx} - ix;
-    const f2 dy = f2{sy, sy} - iy;
-    f2 r2 = (GUARD == GUARD_TINY) ? __builtin_elementwise_fma(dx, dx, f2{kTiny, kTiny}) : dx * dx;
-    r2 = __builtin_elementwise_fma(dy, dy, r2);
-    f2 dz = f2{0.f, 0.f};
-    if (D == 3) {
-        dz = f2{sz, sz} - iz;
-        r2 = __builtin_elementwise_fma(dz, dz, r2);
-    }
-    if (GUARD == GUARD_EXACT) {
-        r2.x = (r2.x < kR2SkipF) ? __builtin_inff() : r2.x;
-        r2.y = (r2.y < kR2SkipF) ? __builtin_inff() : r2.y;
-    }
-    f2 w;
-    w.x = __builtin_amdgcn_rcpf(r2.x);
-    w.y = __builtin_amdgcn_rcpf(r2.y);
-    const f2 t = f2{sm, sm} * w;
-    const f2 s = t * w;
-    ax = __builtin_elementwise_fma(s, dx, ax);
-    ay = __builtin_elementwise_fma(s, dy, ay);
-    if (D == 3) az = __builtin_elementwise_fma(s, dz, az);
-}
-
-// The same for PAIRS target pairs at once, written stage by stage so that the PAIRS dependency chains
-// are interleaved in program order (each v_pk result is consumed PAIRS instructions later).
-template <int D, int PAIRS>
+// Two-vector arithmetic for PAIRS target pairs at once (the two halves of a 64-bit register = two targets),
+// written stage by stage so that the PAIRS dependency chains are interleaved in program order (each v_pk
+// result is consumed PAIRS instructions later).  Per source and target PAIR, D = 3:
+//   ONE_RCP = 0:  v_pk_add x3, v_pk_fma x3 (r^2 + kTiny), v_rcp x2, v_pk_mul x2, v_pk_fma x3      = 13 VALU
+//   ONE_RCP = 1:  the two reciprocals come from ONE v_rcp_f32 of the product: W = 1/(r2a*r2b),
+//                 (1/r2a, 1/r2b) = W * (r2b, r2a)  -- v_mul, v_rcp, v_pk_mul(op_sel swap) instead of v_rcp x2
+//                 (3.45 ns -> 3.0 ns of the 27.7 ns body, tools/ubench_valu.hip).  r2a*r2b must stay finite:
+//                 launched only when every |coordinate| <= kOneRcpMaxCoord (nbx_internal.h).
+template <int D, int PAIRS, int ONE_RCP>
 __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, float sm, const f2 (&ix)[PAIRS],
                                                  const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
                                                  f2 (&ay)[PAIRS], f2 (&az)[PAIRS]) {
@@ -119,8 +88,18 @@ __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dz[q], dz[q], r2[q]);
     }
+    if (ONE_RCP) {
+        float W[PAIRS];
 #pragma unroll
-    for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
+        for (int q = 0; q < PAIRS; ++q) W[q] = r2[q].x * r2[q].y;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) W[q] = __builtin_amdgcn_rcpf(W[q]);
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) w[q] = f2{W[q], W[q]} * __builtin_shufflevector(r2[q], r2[q], 1, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
+    }
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) r2[q] = f2{sm, sm} * w[q];
 #pragma unroll
@@ -255,7 +234,7 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // Flagged (bad) targets are neither stored nor trusted; the launch's extra workgroups
 // (blockIdx.x < close_blocks) evaluate them with the guard (close_set_path below).
 // -------------------------------------------------------------------------------------------------
-template <int D, int PAIRS, int WAVES, int UNROLL, int STAGED = 0>
+template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
@@ -300,13 +279,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll UNROLL
         for (int j = 0; j < kTile; ++j) {
             const float4 s = cur[j];
-            if (STAGED) {
-                interact2_staged<D, PAIRS>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
-            } else {
-#pragma unroll
-                for (int q = 0; q < PAIRS; ++q)
-                    interact2<D, GUARD_TINY>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
-            }
+            interact2_staged<D, PAIRS, ONE_RCP>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
         }
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
@@ -549,120 +522,32 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     for (int q = 0; q < TPL; ++q) out[tgt0 + q * 256u] = (float)o[q];
 }
 
-// -------------------------------------------------------------------------------------------------
-// SMEM variant (exact): no LDS, no barriers.  Source arrays are read with wave-uniform addresses,
-// which hipcc turns into s_load_dwordx8 through the scalar cache; x/y/z/m of a source are then SGPR
-// operands of the VALU instructions.  Kept for A/B: an SGPR source operand slows v_fma_f32 on gfx950.
-// -------------------------------------------------------------------------------------------------
-template <int D, int TPL, int WAVES, int BATCH>
-__global__ __launch_bounds__(256, WAVES) void accel_smem_kernel(KArgs a) {
-    const unsigned tid = threadIdx.x;
-    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
-    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
-
-    float ix[TPL], iy[TPL], iz[TPL];
-    double ox[TPL], oy[TPL], oz[TPL];
-#pragma unroll
-    for (int q = 0; q < TPL; ++q) {
-        const unsigned i = tgt0 + q * 256u;
-        ix[q] = tp[i];
-        iy[q] = tp[(size_t)a.pad + i];
-        iz[q] = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
-        ox[q] = oy[q] = oz[q] = 0.0;
-    }
-
-    unsigned t = blockIdx.y * a.tiles_per_split;
-    unsigned t_end = t + a.tiles_per_split;
-    if (t_end > a.total_tiles) t_end = a.total_tiles;
-    TileWalk w;
-    w.seek(t, a.tiles_per_chunk);
-
-    for (; t < t_end; ++t) {
-        const int c = w.chunk(a.chunk_first, a.chunk_skip);
-        const size_t off = (size_t)c * D * a.pad + w.k * kTile;
-        const float* __restrict__ sxp = a.pos_all + off;
-        const float* __restrict__ syp = sxp + a.pad;
-        const float* __restrict__ szp = sxp + 2 * (size_t)a.pad;
-        const float* __restrict__ smp = a.mass_all + (size_t)c * a.pad + w.k * kTile;
-        float ax[TPL], ay[TPL], az[TPL];
-#pragma unroll
-        for (int q = 0; q < TPL; ++q) ax[q] = ay[q] = az[q] = 0.0f;
-#pragma unroll 1
-        for (int j0 = 0; j0 < kTile; j0 += BATCH) {
-            float sx[BATCH], sy[BATCH], sz[BATCH], sm[BATCH];
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                sx[j] = sxp[j0 + j];
-                sy[j] = syp[j0 + j];
-                sz[j] = (D == 3) ? szp[j0 + j] : 0.0f;
-                sm[j] = smp[j0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-                for (int q = 0; q < TPL; ++q)
-                    interact<D, GUARD_EXACT>(sx[j], sy[j], sz[j], sm[j], ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
-        w.next(a.tiles_per_chunk);
-    }
-
-    float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
-#pragma unroll
-    for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
-}
-
-// ---- variant table --------------------------------------------------------------------------------
-#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0
-#define NBX_SMEM(TPL, WAVES, BATCH) accel_smem_kernel<2, TPL, WAVES, BATCH>, accel_smem_kernel<3, TPL, WAVES, BATCH>, 0, 0
-#define NBX_FAST(PAIRS, WAVES, UNROLL) \
-    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL>, 1, 256
-#define NBX_FASTS(PAIRS, WAVES, UNROLL) \
-    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 1>, 1, 256
-#define NBX_NAME(n) n "_" NBX_STR(NBX_FLAVOUR)
+// ---- variant table: the default fast kernel, its one-reciprocal comparator, and the exact (guarded) kernel ------
+#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0
+#define NBX_FAST(PAIRS, WAVES, UNROLL, ONE_RCP) \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP>, 1, 256, ONE_RCP
 
 const KernelVariant kVariants[] = {
-    {NBX_NAME("lds_t1_w8_exact_u8"), 1, NBX_LDS(1, 8, 8)},
-    {NBX_NAME("lds_t2_w8_exact_u8"), 2, NBX_LDS(2, 8, 8)},
-    {NBX_NAME("lds_t4_w4_exact_u4"), 4, NBX_LDS(4, 4, 4)},
-    {NBX_NAME("smem_t1_w8_exact_b8"), 1, NBX_SMEM(1, 8, 8)},
-    {NBX_NAME("smem_t2_w4_exact_b16"), 2, NBX_SMEM(2, 4, 16)},
-    {NBX_NAME("fastpk_t2_w8_u8"), 2, NBX_FAST(1, 8, 8)},
-    {NBX_NAME("fastpk_t4_w4_u4"), 4, NBX_FAST(2, 4, 4)},
-    {NBX_NAME("fastpk_t4_w8_u4"), 4, NBX_FAST(2, 8, 4)},
-    {NBX_NAME("fastpk_t8_w4_u4"), 8, NBX_FAST(4, 4, 4)},
-    {NBX_NAME("fastpk_t8_w4_u2"), 8, NBX_FAST(4, 4, 2)},
-    {NBX_NAME("fastpk_t8_w4_u8"), 8, NBX_FAST(4, 4, 8)},
-    {NBX_NAME("fastpk_t8_w3_u4"), 8, NBX_FAST(4, 3, 4)},
-    {NBX_NAME("fastpks_t8_w4_u2"), 8, NBX_FASTS(4, 4, 2)},
-    {NBX_NAME("fastpks_t8_w4_u4"), 8, NBX_FASTS(4, 4, 4)},
-    {NBX_NAME("fastpks_t8_w3_u2"), 8, NBX_FASTS(4, 3, 2)},
-    {NBX_NAME("fastpks_t8_w3_u4"), 8, NBX_FASTS(4, 3, 4)},
-    {NBX_NAME("fastpks_t4_w8_u4"), 4, NBX_FASTS(2, 8, 4)},
-    {NBX_NAME("fastpks_t4_w4_u4"), 4, NBX_FASTS(2, 4, 4)},
-    {NBX_NAME("fastpks_t16_w2_u2"), 16, NBX_FASTS(8, 2, 2)},
+    {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
+    {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
+    {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
 };
 
 }  // namespace
-}  // namespace NBX_FLAVOUR
 
-const KernelVariant* NBX_CAT(variants_, NBX_FLAVOUR)(int* count) {
-    *count = (int)(sizeof(NBX_FLAVOUR::kVariants) / sizeof(NBX_FLAVOUR::kVariants[0]));
-    return NBX_FLAVOUR::kVariants;
+const KernelVariant* kernel_variants(int* count) {
+    *count = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+    return kVariants;
 }
 
-#ifdef NBX_EMIT_CLOSE_KERNELS
-// one copy of the close-set helper kernels (emitted by the scalar flavour's translation unit)
 CloseKernels close_kernels() {
     CloseKernels k;
-    k.classify[0] = NBX_FLAVOUR::classify_close_kernel<2>; k.classify[1] = NBX_FLAVOUR::classify_close_kernel<3>;
-    k.classify_src[0] = NBX_FLAVOUR::classify_sources_kernel<2>; k.classify_src[1] = NBX_FLAVOUR::classify_sources_kernel<3>;
-    k.refine[0] = NBX_FLAVOUR::refine_close_kernel<2>;     k.refine[1] = NBX_FLAVOUR::refine_close_kernel<3>;
-    k.scatter[0] = NBX_FLAVOUR::scatter_close_kernel<2>;   k.scatter[1] = NBX_FLAVOUR::scatter_close_kernel<3>;
-    k.potential[0] = NBX_FLAVOUR::potential_kernel<2>;     k.potential[1] = NBX_FLAVOUR::potential_kernel<3>;
+    k.classify[0] = classify_close_kernel<2>; k.classify[1] = classify_close_kernel<3>;
+    k.classify_src[0] = classify_sources_kernel<2>; k.classify_src[1] = classify_sources_kernel<3>;
+    k.refine[0] = refine_close_kernel<2>;     k.refine[1] = refine_close_kernel<3>;
+    k.scatter[0] = scatter_close_kernel<2>;   k.scatter[1] = scatter_close_kernel<3>;
+    k.potential[0] = potential_kernel<2>;     k.potential[1] = potential_kernel<3>;
     return k;
 }
-#endif
 
 }  // namespace nbx

@@ -1,5 +1,5 @@
-// force_launch.hip -- host-side launcher of one force evaluation: merges the variant tables of the two
-// code-generation flavours of force_kernel.hip, checks launch shapes on the host, sizes the grids,
+// force_launch.hip -- host-side launcher of one force evaluation: looks up the variant table of
+// force_kernel.hip, checks launch shapes on the host, sizes the grids,
 // and for fast variants runs the close-set pipeline (classify when positions changed -> fast kernel
 // whose extra workgroups evaluate the close set -> scatter), all asynchronous on the caller's stream with no host read-back.
 #include "nbx_internal.h"
@@ -13,18 +13,18 @@ namespace {
 
 struct Table {
     std::vector<KernelVariant> v;
-    int def = 0, def_exact = 0;
+    int def = 0, def_exact = 0, def_two_rcp = 0;
     CloseKernels ck;
     Table() {
         int n = 0;
-        const KernelVariant* a = variants_scalar(&n);
+        const KernelVariant* a = kernel_variants(&n);
         for (int i = 0; i < n; ++i) v.push_back(a[i]);
-        const KernelVariant* b = variants_slp(&n);
-        for (int i = 0; i < n; ++i) v.push_back(b[i]);
         for (size_t i = 0; i < v.size(); ++i) {
             if (std::strcmp(v[i].name, NBX_DEFAULT_VARIANT) == 0) def = (int)i;
             if (std::strcmp(v[i].name, NBX_DEFAULT_EXACT_VARIANT) == 0) def_exact = (int)i;
         }
+        for (size_t i = v.size(); i-- > 0;)
+            if (v[i].fast && !v[i].needs_extent) def_two_rcp = (int)i;
         ck = close_kernels();
     }
 };
@@ -41,6 +41,8 @@ const char* variant_name(int v) { return valid(v) ? table().v[v].name : "?"; }
 int variant_tpl(int v) { return valid(v) ? table().v[v].tpl : 1; }
 int variant_is_fast(int v) { return valid(v) ? table().v[v].fast : 0; }
 int variant_max_tiles_per_slice(int v) { return valid(v) ? table().v[v].max_tiles_per_slice : 0; }
+int variant_needs_extent(int v) { return valid(v) ? table().v[v].needs_extent : 0; }
+int default_fast_two_rcp_variant() { return table().def_two_rcp; }
 int variant_by_name(const char* name) {
     for (int i = 0; i < num_variants(); ++i)
         if (std::strcmp(table().v[i].name, name) == 0) return i;

@@ -1,0 +1,264 @@
+// leaf_pair_kernel.hip -- SURVEY 8(f-4): batched (target leaf, source leaf) direct sums for the reference's tree
+// codes -- the near-field step either side of the brute-force path:
+//   FMM_Parlay<D>::p2p_phase   nbody-sim-new/fmm_parlay.cpp:916-1022   (law NBX_LAW_FMM_P2P)
+//   BVH leaf loop              nbody-sim-new/bvh.cpp:150-176           (law NBX_LAW_TREE_LEAF)
+//   octree leaf term           nbody-sim-new/octree.cpp:105-125        (law NBX_LAW_TREE_LEAF)
+// and, for completeness, the brute-force law itself over leaf lists (NBX_LAW_BRUTE, methods.cpp:21-37).
+// All three are m_j d / r^4 sums; they differ in sign and in what happens below ~1e-5 separation.
+//
+// Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
+// forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
+// leaf order as SoA fp32 (coalesced streams), and the work is target-leaf-major: one 128-lane workgroup (two
+// wave64) owns up to 128 targets of ONE leaf -- one target per lane, fp32 tile sums flushed into fp64 second-level
+// accumulators -- and walks that leaf's source-leaf list, staging each source leaf through LDS in tiles of 128 bodies
+// {x,y,z,m}; all lanes read the same LDS address (ds_read_b128 broadcast).  No atomics, a fixed summation order
+// (list order, then leaf order), every output written once.  Leaves are small (the reference caps them at 100 bodies,
+// methods.h:26), so the launch is thousands of short workgroups: latency-bound on the lists, not VALU-bound like the
+// brute-force kernel; HBM traffic is 16 B per (target block, source body) served mostly from L2.
+#include "../../include/nbody_hip.h"
+#include "nbx_ctx.h"
+
+#include <cstdio>
+#include <vector>
+
+using namespace nbx;
+
+namespace {
+
+constexpr int kLeafBlock = 128;   // targets per workgroup = source bodies per LDS tile
+
+// smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
+constexpr float kTreeSkipF = 1.0e-9f;    // octree.cpp:119, bvh.cpp:167
+constexpr float kSmoothF = 1.0e-10f;     // fmm_parlay.cpp:1010
+static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10, "fp32 thresholds must not round below the fp64 ones");
+
+struct TargetBlock {
+    uint32_t leaf;     // target leaf
+    uint32_t first;    // first target slot (leaf order)
+    uint32_t count;    // <= kLeafBlock
+};
+
+struct LeafArgs {
+    const float* __restrict__ x;       // [dim][slots] leaf-ordered positions
+    const float* __restrict__ m;       // [slots]
+    uint32_t slots;
+    const uint32_t* __restrict__ leaf_offsets;
+    const uint32_t* __restrict__ list_offsets;
+    const uint32_t* __restrict__ list_sources;
+    const TargetBlock* __restrict__ blocks;
+    double* __restrict__ acc;          // [dim][slots]
+};
+
+template <int D, int LAW>
+__device__ __forceinline__ void leaf_interact(float4 s, float ix, float iy, float iz, float& ax, float& ay, float& az) {
+    const float dx = s.x - ix, dy = s.y - iy, dz = (D == 3) ? s.z - iz : 0.0f;
+    float r2 = __builtin_fmaf(dy, dy, dx * dx);
+    if (D == 3) r2 = __builtin_fmaf(dz, dz, r2);
+    float w;   // weight of d: m_j / r^4 for an ordinary pair
+    if (LAW == NBX_LAW_BRUTE) {
+        const float g = (r2 < kR2SkipF) ? __builtin_inff() : r2;           // methods.cpp:24
+        const float ri = __builtin_amdgcn_rcpf(g);
+        w = s.w * ri * ri;
+    } else if (LAW == NBX_LAW_TREE_LEAF) {
+        // "same position" (every |d_k| <= 1e-9) implies r2 <= 3e-18 < 1e-9: one test covers both skips
+        const float g = (r2 < kTreeSkipF) ? __builtin_inff() : r2;
+        const float ri = __builtin_amdgcn_rcpf(g);
+        w = s.w * ri * ri;
+    } else {
+        const bool same = __builtin_fabsf(dx) <= 1e-14f && __builtin_fabsf(dy) <= 1e-14f && (D == 2 || __builtin_fabsf(dz) <= 1e-14f);
+        if (r2 < kSmoothF) {   // rare: smoothed magnitude, unsmoothed direction (fmm_parlay.cpp:1010-1020, vector.h:93-97)
+            const float r2s = r2 + 1.0e-10f;
+            const float mag = s.w * __builtin_amdgcn_rcpf(r2s) * __builtin_amdgcn_rsqf(r2s);   // m / (r2s * sqrt(r2s))
+            const float inv = (r2 < 1.0e-20f) ? 0.0f : __builtin_amdgcn_rsqf(r2);               // normalized(): 0 below 1e-10
+            w = same ? 0.0f : mag * inv;
+        } else {
+            const float ri = __builtin_amdgcn_rcpf(r2);
+            w = s.w * ri * ri;
+        }
+    }
+    ax = __builtin_fmaf(w, dx, ax);
+    ay = __builtin_fmaf(w, dy, ay);
+    if (D == 3) az = __builtin_fmaf(w, dz, az);
+}
+
+template <int D, int LAW>
+__global__ __launch_bounds__(kLeafBlock) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[kLeafBlock];
+    const unsigned tid = threadIdx.x;
+    const TargetBlock tb = a.blocks[blockIdx.x];
+    const bool valid = tid < tb.count;
+    const uint32_t slot = tb.first + (valid ? tid : 0u);
+    const float ix = a.x[slot], iy = a.x[(size_t)a.slots + slot], iz = (D == 3) ? a.x[2 * (size_t)a.slots + slot] : 0.0f;
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    const uint32_t e0 = a.list_offsets[tb.leaf], e1 = a.list_offsets[tb.leaf + 1];
+    for (uint32_t e = e0; e < e1; ++e) {                       // wave-uniform walk of the leaf's source list
+        const uint32_t s = a.list_sources[e];
+        const uint32_t b0 = a.leaf_offsets[s], b1 = a.leaf_offsets[s + 1];
+        for (uint32_t base = b0; base < b1; base += kLeafBlock) {
+            const uint32_t cnt = (b1 - base < (uint32_t)kLeafBlock) ? b1 - base : (uint32_t)kLeafBlock;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < cnt) {
+                const uint32_t j = base + tid;
+                v.x = a.x[j];
+                v.y = a.x[(size_t)a.slots + j];
+                v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
+                v.w = a.m[j];
+            }
+            __syncthreads();                                   // previous tile fully consumed
+            tile[tid] = v;
+            __syncthreads();
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            if (LAW == NBX_LAW_BRUTE && s == tb.leaf) {
+                // own leaf under the brute-force law: methods.cpp:113 skips i == j by INDEX (a duplicate at the
+                // same position is skipped by the r^2 rule anyway; the index rule matters for r^2 >= 1e-10 only,
+                // which a body never has with itself) -- nothing to do beyond the r^2 rule.
+            }
+            for (uint32_t j = 0; j < cnt; ++j) leaf_interact<D, LAW>(tile[j], ix, iy, iz, ax, ay, az);
+            ox += (double)ax; oy += (double)ay; oz += (double)az;
+        }
+    }
+    if (valid) {
+        a.acc[slot] = ox;
+        a.acc[(size_t)a.slots + slot] = oy;
+        if (D == 3) a.acc[2 * (size_t)a.slots + slot] = oz;
+    }
+}
+
+// staged Body<D> AoS fp64 (host order) -> leaf-ordered SoA fp32
+__global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restrict__ raw, size_t stride_d, int dim,
+                                                          const uint32_t* __restrict__ leaf_bodies, uint32_t slots,
+                                                          float* __restrict__ x, float* __restrict__ m) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= slots) return;
+    const double* __restrict__ b = raw + (size_t)leaf_bodies[s] * stride_d;
+    for (int k = 0; k < dim; ++k) x[(size_t)k * slots + s] = (float)b[k];
+    m[s] = (float)b[2 * dim];
+}
+
+// forces_out[body] = sign * (G m_body) * acc[slot]   (fp64; every body belongs to at most one leaf)
+__global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restrict__ acc, const double* __restrict__ raw, size_t stride_d,
+                                                           int dim, const uint32_t* __restrict__ leaf_bodies, uint32_t slots, double signedG,
+                                                           double* __restrict__ forces) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= slots) return;
+    const uint32_t body = leaf_bodies[s];
+    const double gm = signedG * raw[(size_t)body * stride_d + 2 * dim];
+    for (int k = 0; k < dim; ++k) forces[(size_t)body * dim + k] = gm * acc[(size_t)k * slots + s];
+}
+
+typedef void (*LeafKernel)(LeafArgs);
+LeafKernel pick(int dim, int law) {
+    static const LeafKernel table[2][3] = {
+        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
+    return table[dim - 2][law];
+}
+
+struct DeviceBuffers {   // frees whatever was allocated when the call leaves, on every path
+    std::vector<void*> ptrs;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~DeviceBuffers() {
+        for (void* p : ptrs) (void)hipFree(p);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace
+
+extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, const uint32_t* leaf_offsets,
+                                    const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                                    const uint32_t* list_sources, int law, double G, int device, double* forces_out,
+                                    float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if ((!bodies || !forces_out) && n) return fail(NBX_ERR_INVALID, "null argument");
+    if (n > ((size_t)1 << 31) || n_leaves > ((size_t)1 << 31)) return fail(NBX_ERR_INVALID, "too many bodies / leaves");
+    const size_t min_stride = (size_t)(2 * dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    if (n_leaves && (!leaf_offsets || !list_offsets)) return fail(NBX_ERR_INVALID, "null leaf arrays");
+    // ---- host-side validation of the CSR structure: every index the kernel will follow is checked here ----
+    const size_t slots = n_leaves ? leaf_offsets[n_leaves] : 0;
+    const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
+    if (n_leaves && (leaf_offsets[0] != 0 || list_offsets[0] != 0)) return fail(NBX_ERR_INVALID, "CSR offsets must start at 0");
+    for (size_t l = 0; l < n_leaves; ++l)
+        if (leaf_offsets[l + 1] < leaf_offsets[l] || list_offsets[l + 1] < list_offsets[l]) return fail(NBX_ERR_INVALID, "CSR offsets must be non-decreasing");
+    if ((slots && !leaf_bodies) || (n_list && !list_sources)) return fail(NBX_ERR_INVALID, "null leaf arrays");
+    {
+        std::vector<unsigned char> seen(n, 0);
+        for (size_t s = 0; s < slots; ++s) {
+            const uint32_t b = leaf_bodies[s];
+            if (b >= n) return fail(NBX_ERR_INVALID, "leaf_bodies entry out of range");
+            if (seen[b]) return fail(NBX_ERR_INVALID, "a body may belong to at most one leaf");
+            seen[b] = 1;
+        }
+    }
+    for (size_t e = 0; e < n_list; ++e)
+        if (list_sources[e] >= n_leaves) return fail(NBX_ERR_INVALID, "list_sources entry out of range");
+    for (size_t i = 0; i < n * (size_t)dim; ++i) forces_out[i] = 0.0;   // bodies in no leaf: zero force
+    int ndev = 0;
+    int rc = nbx_device_count(&ndev);
+    if (rc != NBX_OK) return rc;
+    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
+    if (slots == 0) return NBX_OK;
+
+    std::vector<TargetBlock> blocks;
+    for (size_t l = 0; l < n_leaves; ++l)
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += kLeafBlock)
+            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < (uint32_t)kLeafBlock) ? leaf_offsets[l + 1] - f : (uint32_t)kLeafBlock});
+
+    NBX_HIP_TRY(hipSetDevice(device));
+    DeviceBuffers d;
+    NBX_HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    NBX_HIP_TRY(hipEventCreate(&d.ev0));
+    NBX_HIP_TRY(hipEventCreate(&d.ev1));
+    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e == hipSuccess) d.ptrs.push_back(*p);
+        return e;
+    };
+    double *raw = nullptr, *acc = nullptr, *dforces = nullptr;
+    float *x = nullptr, *m = nullptr;
+    uint32_t *d_lo = nullptr, *d_lb = nullptr, *d_so = nullptr, *d_ss = nullptr;
+    TargetBlock* d_blocks = nullptr;
+    NBX_HIP_TRY(dalloc((void**)&raw, n * stride_bytes));
+    NBX_HIP_TRY(dalloc((void**)&x, (size_t)dim * slots * sizeof(float)));
+    NBX_HIP_TRY(dalloc((void**)&m, slots * sizeof(float)));
+    NBX_HIP_TRY(dalloc((void**)&acc, (size_t)dim * slots * sizeof(double)));
+    NBX_HIP_TRY(dalloc((void**)&dforces, n * (size_t)dim * sizeof(double)));
+    NBX_HIP_TRY(dalloc((void**)&d_lo, (n_leaves + 1) * sizeof(uint32_t)));
+    NBX_HIP_TRY(dalloc((void**)&d_lb, slots * sizeof(uint32_t)));
+    NBX_HIP_TRY(dalloc((void**)&d_so, (n_leaves + 1) * sizeof(uint32_t)));
+    NBX_HIP_TRY(dalloc((void**)&d_ss, n_list * sizeof(uint32_t)));
+    NBX_HIP_TRY(dalloc((void**)&d_blocks, blocks.size() * sizeof(TargetBlock)));
+    NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_lo, leaf_offsets, (n_leaves + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_lb, leaf_bodies, slots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_so, list_offsets, (n_leaves + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    if (n_list) NBX_HIP_TRY(hipMemcpyAsync(d_ss, list_sources, n_list * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(TargetBlock), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemsetAsync(dforces, 0, n * (size_t)dim * sizeof(double), d.stream));
+    (void)hipGetLastError();
+    const unsigned gs = (unsigned)((slots + 255) / 256);
+    hipLaunchKernelGGL(leaf_gather_kernel, dim3(gs), dim3(256), 0, d.stream, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots, x, m);
+    NBX_HIP_TRY(hipGetLastError());
+    LeafArgs a;
+    a.x = x; a.m = m; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
+    a.blocks = d_blocks; a.acc = acc;
+    NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
+    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kLeafBlock), 0, d.stream, a);
+    NBX_HIP_TRY(hipGetLastError());
+    NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
+    const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
+    hipLaunchKernelGGL(leaf_scatter_kernel, dim3(gs), dim3(256), 0, d.stream, acc, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots,
+                       signedG, dforces);
+    NBX_HIP_TRY(hipGetLastError());
+    NBX_HIP_TRY(hipMemcpyAsync(forces_out, dforces, n * (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+    NBX_HIP_TRY(hipStreamSynchronize(d.stream));
+    if (kernel_ms) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, d.ev0, d.ev1));
+    return NBX_OK;
+}

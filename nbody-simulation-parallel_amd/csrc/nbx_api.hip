@@ -67,6 +67,7 @@ int ensure_stage(nbx_ctx* c, size_t bytes) {
 int effective_variant(const nbx_ctx* c) {
     int v = c->variant_req >= 0 ? c->variant_req : default_variant();
     if (variant_is_fast(v) && c->force_exact) v = default_exact_variant();
+    else if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
     return v;
 }
 
@@ -295,12 +296,13 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     {
         const char* base = static_cast<const char*>(bodies);
         const size_t lo = (size_t)c->shard * c->shard_len;
-        double mmax = 0.0;
+        double mmax = 0.0, cmax = 0.0;
         size_t close = 0;
         for (size_t i = 0; i < c->n_total; ++i) {
             const double* b = reinterpret_cast<const double*>(base + i * stride_bytes);
             const double m = b[2 * c->dim] < 0 ? -b[2 * c->dim] : b[2 * c->dim];
             if (!(m <= mmax)) mmax = m;  // also catches NaN
+            for (int k = 0; k < c->dim; ++k) { const double v = b[k] < 0 ? -b[k] : b[k]; if (!(v <= cmax)) cmax = v; }
             if (i >= lo && i < lo + c->count) {
                 double cm = b[0] < 0 ? -b[0] : b[0];
                 for (int k = 1; k < c->dim; ++k) { const double v = b[k] < 0 ? -b[k] : b[k]; if (v < cm) cm = v; }
@@ -308,6 +310,7 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
             }
         }
         c->force_exact = !(mmax <= kFastMaxMass) || close * 8 > c->count;
+        c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
     }
     const size_t bytes = c->n_total * stride_bytes;
     rc = ensure_stage(c, bytes ? bytes : 8);

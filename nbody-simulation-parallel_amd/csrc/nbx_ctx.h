@@ -47,6 +47,7 @@ struct nbx_ctx {
     bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
     int tgt_cand_valid = 0;     // the device's candidate-target list matches the own chunk's positions
     int bad_list_pass = -1;     // NBX_SRC_* pass whose bad-target list is on the device (-1: none / stale)
+    bool extent_ok = false;     // every |coordinate| <= kOneRcpMaxCoord at upload (one-reciprocal kernel allowed)
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
     // boundary staging

@@ -50,6 +50,10 @@ constexpr unsigned kRefineLimit = 131072;  // candidate targets beyond this are 
 constexpr unsigned long long kRefinePairLimit = 1ull << 36;  // same for (candidate targets) x (candidate sources)
 // m / (kTiny^2) must stay finite in fp32 for a coincident source: masses above this force the exact path.
 constexpr double kFastMaxMass = 1.0e10;
+// One-reciprocal fast variant: W = 1/(r2a*r2b) must stay finite.  With every |coordinate| <= X, r^2 <= 12 X^2 and
+// the product <= 144 X^4; X = 1e9 would still fit (1.4e38), 1e8 leaves a 10x margin for bodies that drift after
+// the upload-time check.  Violations fall back to the two-reciprocal fast kernel (same results to ~2 ulp).
+constexpr double kOneRcpMaxCoord = 1.0e8;
 constexpr int kCloseBlocksX = 32;          // extra workgroups per source slice that a fast launch adds for bad targets
 
 // How one force evaluation walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
@@ -117,10 +121,10 @@ struct KernelVariant {
     void (*k3)(KArgs);    // D = 3
     int fast;             // 1: unguarded fast kernel + close-set pipeline (exact overall)
     int max_tiles_per_slice;  // > 0: the kernel's fp32 second-level sums want at most this many tiles per slice
+    int needs_extent;     // 1: only valid while every |coordinate| <= kOneRcpMaxCoord (one-reciprocal kernel)
 };
-// force_kernel.hip, compiled once per code-generation flavour
-const KernelVariant* variants_slp(int* count);
-const KernelVariant* variants_scalar(int* count);
+// force_kernel.hip
+const KernelVariant* kernel_variants(int* count);
 struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
@@ -133,6 +137,8 @@ const char* variant_name(int variant);
 int variant_tpl(int variant);
 int variant_is_fast(int variant);
 int variant_max_tiles_per_slice(int variant);
+int variant_needs_extent(int variant);
+int default_fast_two_rcp_variant();   // fast variant without the extent precondition
 int variant_by_name(const char* name);
 int default_variant();        // the fast default
 int default_exact_variant();  // used when the fast path's preconditions do not hold

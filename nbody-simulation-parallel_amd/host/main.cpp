@@ -107,6 +107,16 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
         bool enabled;
         std::function<Forces()> solve;
     };
+    // GPU-count dimension of the sweep: the one-GPU row keeps the plain label; a row sharded over
+    // G ranks is BruteForce_HIP_x<G>, so the reference's notebook groups the counts as separate methods.
+    const int hip_ranks = opt.devices.size() > 1 ? static_cast<int>(opt.devices.size()) : 1;
+    const std::string hip_label = hip_ranks > 1 ? "BruteForce_HIP_x" + std::to_string(hip_ranks) : std::string("BruteForce_HIP");
+    int distinct_devices = 1;
+    if (hip_ranks > 1) {
+        std::vector<int> u = opt.devices;
+        std::sort(u.begin(), u.end());
+        distinct_devices = static_cast<int>(std::unique(u.begin(), u.end()) - u.begin());
+    }
     const std::vector<Method> table = {
         {"BruteForce_Sequential", "Brute force O(n²) sequential approach:", false, run_cpu_bf,
          [&] { return brute_force_seq_n_body<D>(bodies); }},
@@ -114,7 +124,7 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
          [&] { return brute_force_omp_n_body_1<D>(bodies); }},
         {"BruteForce_OpenMP2", "Brute force OpenMP parallel approach (memory-efficient):", true, run_cpu_bf,
          [&] { return brute_force_omp_n_body_2<D>(bodies); }},
-        {"BruteForce_HIP", "Brute force HIP (MI355X, fp32 tiled all-pairs) approach:", false, run_hip,
+        {hip_label.c_str(), "Brute force HIP (MI355X, fp32 tiled all-pairs) approach:", false, run_hip,
          [&] { return brute_force_hip_n_body<D>(bodies); }},
     };
 
@@ -134,15 +144,15 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
             csv << std::endl;
             out << "Time taken: " << seconds << " s" << std::endl;
             if (opt.accuracy) out << "Accuracy: " << std::to_string(accuracy) << "%" << std::endl;
-            if (std::string(method.label) == "BruteForce_HIP") {
+            if (method.label == hip_label) {
                 const double kernel_s = last_hip_run_info().kernel_ms * 1e-3;
                 const double pairs = static_cast<double>(n) * static_cast<double>(n);
                 out << "Kernel time: " << kernel_s << " s  (" << pairs / kernel_s << " pair-interactions/s, "
                     << 100.0 * pairs * 20.0 / kernel_s / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
                 hipcsv.open(base + "_hip.csv");
-                hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec" << std::endl
+                hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec,GPUs,DistinctDevices" << std::endl
                        << method.label << "," << n << "," << D << "," << std::fixed << std::setprecision(6) << seconds << ","
-                       << kernel_s << "," << std::scientific << pairs / kernel_s << std::endl;
+                       << kernel_s << "," << std::scientific << pairs / kernel_s << "," << hip_ranks << "," << distinct_devices << std::endl;
             }
             print_validation_forces<D>(forces, n, log);
             print_validation_forces<D>(forces, n, std::cout);
@@ -211,6 +221,7 @@ void usage(const char* argv0) {
               << "      --energy-every <k> Log total energy and |dE/E0| every k steps (potential matching the reference law)" << std::endl
               << "      --gpus <g>      Shard the HIP rows over GPUs 0..g-1 of this node (one process, RCCL all-gather per step)" << std::endl
               << "      --devices <list> Same with an explicit device list, e.g. 0,0,0 = three virtual ranks on GPU 0" << std::endl
+              << "      --device-count  Print the number of HIP devices and exit" << std::endl
               << "      --dump <prefix> Write bodies and every method's forces as raw doubles (<prefix>_<Method>.f64)" << std::endl
               << "  -h, --help          Display this help message" << std::endl;
 }
@@ -281,6 +292,9 @@ int main(int argc, char* argv[]) {
                 std::cerr << "Error: --init must be uniform or plummer" << std::endl;
                 return 1;
             }
+        } else if (arg == "--device-count") {   // for scripts: how many HIP devices this node offers
+            std::cout << hip_device_count() << std::endl;
+            return 0;
         } else if (arg == "-h" || arg == "--help") {
             usage(argv[0]);
             return 0;

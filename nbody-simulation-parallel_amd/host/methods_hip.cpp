@@ -40,6 +40,10 @@ bool warm_up_hip() {
     else ok = nbx_warmup(device_ordinal()) == NBX_OK;
     return ok;
 }
+int hip_device_count() {
+    int n = 0;
+    return nbx_device_count(&n) == NBX_OK ? n : 0;
+}
 void set_hip_device(int device) { g_device = device; }
 void set_hip_devices(const std::vector<int>& devices) { g_devices = devices; }
 

@@ -61,6 +61,9 @@ const HipRunInfo& last_hip_run_info();
 // Returns false (and changes nothing) if no device is usable -- the solver calls will then throw.
 bool warm_up_hip();
 
+// Number of HIP devices visible (0 when there is none or the runtime fails).
+int hip_device_count();
+
 // Device ordinal used by the two entry points above (default 0; NBODY_HIP_DEVICE overrides).
 void set_hip_device(int device);
 

@@ -362,3 +362,106 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ---- leaf-pair direct sums of the reference's tree codes --------------------------------
+ *
+ * The near-field ("P2P") step of the reference's tree methods is a batch of small all-pairs sums: every body
+ * of a target leaf against every body of each source leaf on that leaf's list.  Three per-pair laws occur:
+ *
+ *   law 0  BRUTE     nbody-sim-new/methods.cpp:21-37 (the brute-force law above; repulsive: forces[i] -= f)
+ *   law 1  TREE_LEAF nbody-sim-new/octree.cpp:105-125 (single-body leaf of the Barnes-Hut octree) and
+ *                    nbody-sim-new/bvh.cpp:150-176 (BVH leaf loop): skip when every |d_k| <= 1e-9 ("same
+ *                    position"), skip when dist_sq < 1e-9, else force += (diff/|diff|) * ((G*mi)*mj)/(dist_sq*dist)
+ *                    -- attractive (diff = other - body, added).
+ *   law 2  FMM_P2P   nbody-sim-new/fmm_parlay.cpp:992-1021: skip when every |d_k| <= 1e-14; dist_sq < 1e-10 is
+ *                    NOT skipped but smoothed: dist_sq += (1e-5)^2 before the magnitude; the direction stays
+ *                    diff.normalized() of the unsmoothed diff (zero vector below 1e-10, vector.h:93-97); attractive.
+ *
+ * Parity status: law 0 pinned as above; law 1 pinned against the reference's own octree object code evaluated with
+ * theta = 0 (every leaf visited: oracle/ref_driver.cpp ref_octree_direct_forces, tests/test_oracle_vs_ref.py) to fp64
+ * re-association noise (the tree visits sources in its own order); law 2 PARITY UNPINNED -- restated from the cited
+ * lines only: FMM_Parlay<D>'s constructor leaves its tree pointing into a destroyed local vector
+ * (fmm_parlay.cpp:16-22 with fmm.cpp:389-395), so executing the reference's p2p_phase is undefined behaviour and is
+ * not done.  The batching (CSR leaf lists) is this build's own; the reference walks pointers.
+ *
+ * leaf l owns the bodies leaf_bodies[leaf_offsets[l] .. leaf_offsets[l+1]) (indices into `bodies`; a body belongs to
+ * at most one leaf); target leaf t sums over the source leaves list_sources[list_offsets[t] .. list_offsets[t+1]) in
+ * list order, bodies in leaf order.  forces[n*D] (zero for bodies in no leaf).
+ */
+static inline void leaf_pair_term(const double* pi, const double* pj, double mi, double mj, int D, int law, double* acc) {
+    double diff[3], dist_sq = 0.0;
+    for (int k = 0; k < D; ++k) diff[k] = pj[k] - pi[k];
+    if (law == 0) {
+        double f[3];
+        if (!pair_force(pi, pj, mi, mj, D, f)) return;
+        for (int k = 0; k < D; ++k) acc[k] -= f[k];
+        return;
+    }
+    const double same_tol = (law == 1) ? 1e-9 : 1e-14;
+    int same = 1;
+    for (int k = 0; k < D; ++k) if (fabs(diff[k]) > same_tol) { same = 0; break; }
+    if (same) return;
+    for (int k = 0; k < D; ++k) dist_sq += diff[k] * diff[k];
+    const double mag = sqrt(dist_sq);                 /* diff.normalized(): of the unsmoothed diff */
+    if (law == 1) {
+        if (dist_sq < 1e-9) return;                   /* octree.cpp:119, bvh.cpp:167 */
+    } else if (dist_sq < 1e-10) {
+        const double epsilon = 1e-5;                  /* fmm_parlay.cpp:1010-1013 */
+        dist_sq += epsilon * epsilon;
+    }
+    const double dist = sqrt(dist_sq);
+    const double force_mag = ORACLE_G * mi * mj / (dist_sq * dist);
+    if (mag < 1e-10) return;                          /* normalized() returns the zero vector */
+    for (int k = 0; k < D; ++k) acc[k] += (diff[k] / mag) * force_mag;
+}
+
+int oracle_leaf_pair_forces(const double* bodies, size_t n, int D, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies,
+                            size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources, int law, double* forces) {
+    if ((D != 2 && D != 3) || law < 0 || law > 2) return -1;
+    for (size_t i = 0; i < n * (size_t)D; ++i) forces[i] = 0.0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t t = 0; t < n_leaves; ++t) {
+        for (uint32_t a = leaf_offsets[t]; a < leaf_offsets[t + 1]; ++a) {
+            const size_t i = leaf_bodies[a];
+            double acc[3] = {0.0, 0.0, 0.0};
+            for (uint32_t e = list_offsets[t]; e < list_offsets[t + 1]; ++e) {
+                const uint32_t s = list_sources[e];
+                for (uint32_t b = leaf_offsets[s]; b < leaf_offsets[s + 1]; ++b) {
+                    const size_t j = leaf_bodies[b];
+                    if (law == 0 && i == j) continue;  /* methods.cpp:113 */
+                    leaf_pair_term(POS(bodies, i, D), POS(bodies, j, D), MASS(bodies, i, D), MASS(bodies, j, D), D, law, acc);
+                }
+            }
+            for (int k = 0; k < D; ++k) forces[i * D + k] = acc[k];
+        }
+    }
+    return 0;
+}
+
+/* sum_j |f_ij| over the same pairs (condition numbers for the stated fp32 tolerance) */
+int oracle_leaf_pair_magnitude_sums(const double* bodies, size_t n, int D, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies,
+                                    size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources, int law, double* sums) {
+    if ((D != 2 && D != 3) || law < 0 || law > 2) return -1;
+    for (size_t i = 0; i < n; ++i) sums[i] = 0.0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t t = 0; t < n_leaves; ++t) {
+        for (uint32_t a = leaf_offsets[t]; a < leaf_offsets[t + 1]; ++a) {
+            const size_t i = leaf_bodies[a];
+            double s_acc = 0.0;
+            for (uint32_t e = list_offsets[t]; e < list_offsets[t + 1]; ++e) {
+                const uint32_t s = list_sources[e];
+                for (uint32_t b = leaf_offsets[s]; b < leaf_offsets[s + 1]; ++b) {
+                    const size_t j = leaf_bodies[b];
+                    if (law == 0 && i == j) continue;
+                    double acc[3] = {0.0, 0.0, 0.0};
+                    leaf_pair_term(POS(bodies, i, D), POS(bodies, j, D), MASS(bodies, i, D), MASS(bodies, j, D), D, law, acc);
+                    double m2 = 0.0;
+                    for (int k = 0; k < D; ++k) m2 += acc[k] * acc[k];
+                    s_acc += sqrt(m2);
+                }
+            }
+            sums[i] = s_acc;
+        }
+    }
+    return 0;
+}

@@ -91,6 +91,31 @@ int ref_time_brute_force(int variant, const double* bodies, size_t n, int D, dou
 
 int ref_parlay_num_workers() { return (int)parlay::num_workers(); }
 
+// The reference's Barnes-Hut octree (octree.cpp) evaluated with theta = 0: the acceptance test
+// `2*half_size/dist < theta` (octree.cpp:146) never holds, so every body is reached through its single-body
+// leaf (octree.cpp:105-125) -- an all-pairs sum under the tree codes' attractive leaf law, in the tree's visiting
+// order.  Pins law 1 of oracle_leaf_pair_forces.  (The methods.cpp wrappers ignore their theta argument and use the
+// global BARNES_HUT_THETA, methods.cpp:228-233, hence the direct call on the public root.)
+int ref_octree_direct_forces(const double* bodies, size_t n, int D, double* out) {
+    if (D == 2) {
+        auto b = wrap<2>(bodies, n);
+        Octree<2> tree(b);
+        std::vector<Vector<2>> f(n);
+        for (size_t i = 0; i < n; ++i) f[i] = tree.root->calculate_force(b[i], 0.0);
+        unwrap<2>(f, out);
+        return 0;
+    }
+    if (D == 3) {
+        auto b = wrap<3>(bodies, n);
+        Octree<3> tree(b);
+        std::vector<Vector<3>> f(n);
+        for (size_t i = 0; i < n; ++i) f[i] = tree.root->calculate_force(b[i], 0.0);
+        unwrap<3>(f, out);
+        return 0;
+    }
+    return -1;
+}
+
 int ref_update_body_velocities(double* bodies, const double* f, size_t n, int D, double dt) {
     if (D == 2) {
         auto b = wrap<2>(bodies, n);

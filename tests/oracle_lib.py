@@ -114,6 +114,24 @@ class Oracle:
     def num_threads(self):
         return self.lib.oracle_num_threads()
 
+    # ---- leaf-pair direct sums (law 0 brute force, 1 tree leaf, 2 FMM P2P) ----
+    def _leaf_call(self, fn, bodies, leaves, law, width):
+        d = self._dim(bodies)
+        lo, lb, so, ss = (np.ascontiguousarray(a, dtype=np.uint32) for a in leaves)
+        out = np.zeros((bodies.shape[0], width) if width > 1 else bodies.shape[0], dtype=np.float64)
+        u32 = ctypes.POINTER(ctypes.c_uint32)
+        rc = fn(_p(bodies), _sz(bodies.shape[0]), d, lo.ctypes.data_as(u32), lb.ctypes.data_as(u32), _sz(lo.size - 1),
+                so.ctypes.data_as(u32), ss.ctypes.data_as(u32), law, _p(out))
+        assert rc == 0
+        return out
+
+    def leaf_pair_forces(self, bodies, leaves, law):
+        """leaves = (leaf_offsets, leaf_bodies, list_offsets, list_sources), CSR as in include/nbody_hip.h."""
+        return self._leaf_call(self.lib.oracle_leaf_pair_forces, bodies, leaves, law, self._dim(bodies))
+
+    def leaf_pair_magnitude_sums(self, bodies, leaves, law):
+        return self._leaf_call(self.lib.oracle_leaf_pair_magnitude_sums, bodies, leaves, law, 1)
+
 
 class Reference:
     """The reference's own object code (only where oracle/build_ref.sh produced it).  The library
@@ -148,6 +166,13 @@ class Reference:
         d = (bodies.shape[1] - 1) // 2
         f = np.zeros((bodies.shape[0], d), dtype=np.float64)
         assert self.lib.ref_brute_force(variant, _p(bodies), _sz(bodies.shape[0]), d, _p(f)) == 0
+        return f
+
+    def octree_direct_forces(self, bodies):
+        """Reference octree (octree.cpp) walked with theta = 0: all-pairs under the tree codes' leaf law."""
+        d = (bodies.shape[1] - 1) // 2
+        f = np.zeros((bodies.shape[0], d), dtype=np.float64)
+        assert self.lib.ref_octree_direct_forces(_p(bodies), _sz(bodies.shape[0]), d, _p(f)) == 0
         return f
 
     def time_brute_force(self, variant, bodies):

@@ -58,7 +58,9 @@ def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
     p = _run(tmp_path, "-N", str(n), "-m", "g", "--seed", "6", "--steps", "2", "--dt", "3", "--devices", "0,0,0", "--dump", "d")
     assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
     bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
-    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
+    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP_x3.f64")).reshape(n, 3)   # sharded rows carry the rank count
+    csv = glob.glob(os.path.join(tmp_path, "results", f"run_*_N_{n}_3D.csv"))[0]
+    assert any(l.startswith(f"BruteForce_HIP_x3,{n},3,") for l in open(csv).read().splitlines())
     br = oracle.round_inputs_to_f32(bodies)
     rows = np.arange(0, n, 97)
     assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "sharded harness rows")
@@ -76,3 +78,25 @@ def test_plummer_energy_logging(tmp_path):
     drifts = [float(x) for x in re.findall(r"\|dE/E0\| = ([0-9.eE+-]+)", p.stdout)]
     assert len(drifts) == 5 and max(drifts) < 0.1, p.stdout
     assert re.search(r"step 0  E = ", p.stdout)
+
+
+def test_sweep_over_gpu_counts(tmp_path):
+    """tools/run_sweep.sh with a GPU-count dimension (run_simulations.sh:26-60): two sizes x {1, 2} GPUs
+    (2 = two virtual ranks on the one device, the same sharded path) + one accuracy run; the aggregate keeps the
+    reference's four columns (analysis/aggregated_results.csv:1) and the sidecar carries the GPU count."""
+    import csv
+    env = dict(os.environ, SIZES="20000 60000", GPU_COUNTS="1 2", DIMS="3", ACC_SIZES="2000")
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_sweep.sh"), "--seed", "4"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "failed" not in p.stdout, p.stdout + p.stderr
+    agg = list(csv.DictReader(open(os.path.join(tmp_path, "results", "aggregated_results.csv"))))
+    assert list(agg[0].keys()) == ["Bodies", "Method", "Dimension", "Average Runtime (s)"]
+    methods = {(int(r["Bodies"]), r["Method"]) for r in agg}
+    for n in (20000, 60000):
+        assert (n, "BruteForce_HIP") in methods and (n, "BruteForce_HIP_x2") in methods
+    assert (2000, "BruteForce_Sequential") in methods and (2000, "BruteForce_HIP") in methods
+    hip = list(csv.DictReader(open(os.path.join(tmp_path, "results", "aggregated_hip.csv"))))
+    counts = {(int(r["Bodies"]), int(r["GPUs"])): r for r in hip}
+    for n in (20000, 60000):
+        assert counts[(n, 1)]["Distinct Devices"] == "1" and counts[(n, 2)]["Distinct Devices"] == "1"
+        assert float(counts[(n, 2)]["Pair Interactions/s (kernel)"]) > 0 and counts[(n, 2)]["Kernel Speed-up vs 1 GPU"] != ""

@@ -308,6 +308,36 @@ def test_fast_path_preconditions_fall_back_to_guarded_kernel(nbx, oracle):
         assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(cr), oracle.force_magnitude_sums(cr), "after drift")
 
 
+def test_one_reciprocal_variant_extent_precondition(nbx, oracle):
+    """fastpk1r (one v_rcp_f32 per two pairs: W = 1/(r2a*r2b)) is only launched while every |coordinate| <= 1e8, so the
+    product cannot overflow; beyond that the library substitutes the two-reciprocal fast kernel.  Both sides of the
+    switch against the oracle, including separations of ~2e9 where the product WOULD overflow."""
+    one = [i for i, n in enumerate(nbx.variants()) if n.startswith("fastpk1r")][0]
+    n, dim = 4096, 3
+    b = oracle.generate(77, n, dim)
+    b[:, :3] = (b[:, :3] - 5.0e6) * 18.0                         # |coordinates| up to 9e7 < 1e8: separations up to 3e8
+    b[5, :3] = b[4, :3]                                          # coincident pair: r^2 = kTiny on one side of the product
+    b = oracle.round_inputs_to_f32(b)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_tuning(0, one)
+        assert c.effective_tuning()[0].startswith("fastpk1r")
+        c.compute_accel()
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "one-rcp inside the extent")
+    for scale in (30.0, 250.0):                                  # |coordinates| up to 1.5e8 / 1.2e9 (r2a*r2b up to 3e38: would overflow)
+        big = oracle.generate(78, n, dim)
+        big[:, :3] = (big[:, :3] - 5.0e6) * scale
+        big = oracle.round_inputs_to_f32(big)
+        with nbx.Context(n, dim) as c:
+            c.upload(big)
+            c.set_tuning(0, one)
+            assert c.effective_tuning()[0].startswith("fastpk_"), "extent precondition must demote the one-reciprocal kernel"
+            c.compute_accel()
+            f = c.forces(oracle.G)
+        assert np.isfinite(f).all()
+        assert_force_parity(f, oracle.brute_force_seq(big), oracle.force_magnitude_sums(big), f"extent x{scale:g}")
+
+
 def test_signed_and_extreme_coordinates(nbx, oracle):
     """Bodies on both sides of the coordinate planes, at the origin, and spread over 12 decades of
     separation: the candidate test works on |coordinate| and the fp32 path must neither overflow nor
@@ -326,8 +356,6 @@ def test_signed_and_extreme_coordinates(nbx, oracle):
     ref = oracle.brute_force_seq(b)
     S = oracle.force_magnitude_sums(b)
     for v, name in enumerate(nbx.variants()):
-        if not (name.startswith("fastpks_t8_w4_u4") or name.startswith("lds_t1_w8")):
-            continue
         with nbx.Context(n, dim) as c:
             c.upload(b)
             c.set_tuning(0, v)
@@ -382,7 +410,7 @@ def test_fast_path_boundary_pairs(nbx, oracle):
     b = oracle.round_inputs_to_f32(b)
     ref = oracle.brute_force_seq(b)
     S = oracle.force_magnitude_sums(b)
-    for v, name in _fast_variants(nbx)[:3] + [(-1, "default")]:
+    for v, name in _fast_variants(nbx) + [(-1, "default")]:
         with nbx.Context(n, dim) as c:
             c.upload(b)
             c.set_tuning(0, v)

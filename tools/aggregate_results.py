@@ -2,7 +2,9 @@
 """Average the per-run CSVs written by nbody_sim (results/run_*_N_*_*D.csv) into one table with the columns
 of the reference's analysis/aggregated_results.csv -- `Bodies,Method,Dimension,Average Runtime (s)` -- so the
 BruteForce_HIP rows no longer have to be typed in by hand (the reference notebook's cell 4 did that for its
-CUDA numbers).  A second file carries kernel time and pair-interactions/s from the *_hip.csv sidecars.
+CUDA numbers; rows sharded over G GPUs carry the label BruteForce_HIP_x<G>).  A second file, aggregated_hip.csv,
+carries the GPU count, kernel time, pair-interactions/s and the speed-up over the one-GPU row from the *_hip.csv
+sidecars (per-N rows for 1/2/4/8 GPUs).
     python tools/aggregate_results.py [results_dir]"""
 import csv
 import glob
@@ -33,17 +35,21 @@ def main():
     for path in sorted(glob.glob(os.path.join(d, "run_*_hip.csv"))):
         with open(path) as f:
             for row in csv.DictReader(f):
-                hip[(int(row["Bodies"]), int(row["Dimension"]))].append(
-                    (float(row["Time(s)"]), float(row["KernelTime(s)"]), float(row["PairInteractionsPerSec"])))
+                key = (int(row["Bodies"]), int(row["Dimension"]), int(row.get("GPUs", 1) or 1), int(row.get("DistinctDevices", 1) or 1))
+                hip[key].append((float(row["Time(s)"]), float(row["KernelTime(s)"]), float(row["PairInteractionsPerSec"])))
+    one_gpu = {(n, dim): sum(r[1] for r in rows) / len(rows) for (n, dim, g, dd), rows in hip.items() if g == 1}
     out2 = os.path.join(d, "aggregated_hip.csv")
     with open(out2, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Bodies", "Dimension", "Runs", "Average Runtime (s)", "Average Kernel Time (s)", "Pair Interactions/s (kernel)",
-                    "Fraction of MI355X fp32 peak (20 flop/pair)"])
-        for (n, dim), rows in sorted(hip.items()):
+        w.writerow(["Bodies", "Dimension", "GPUs", "Distinct Devices", "Runs", "Average Runtime (s)", "Average Kernel Time (s)",
+                    "Pair Interactions/s (kernel)", "Fraction of fp32 peak of the GPUs used (20 flop/pair)", "Kernel Speed-up vs 1 GPU"])
+        for (n, dim, g, dd), rows in sorted(hip.items()):
             k = len(rows)
             rate = sum(r[2] for r in rows) / k
-            w.writerow([n, dim, k, sum(r[0] for r in rows) / k, sum(r[1] for r in rows) / k, rate, rate * 20 / 157.3e12])
+            kern = sum(r[1] for r in rows) / k
+            base = one_gpu.get((n, dim))
+            w.writerow([n, dim, g, dd, k, sum(r[0] for r in rows) / k, kern, rate, rate * 20 / (157.3e12 * dd),
+                        base / kern if base and kern > 0 else ""])
     print(f"wrote {out} ({len(runs)} rows) and {out2} ({len(hip)} rows)")
 
 

@@ -2,18 +2,15 @@
    python tools/time_variants.py [N] [rounds] [name-substring ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import nbody_amd as nbx
-from oracle_lib import Oracle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 pats = sys.argv[3:]
 names = nbx.variants()
 sel = [i for i, nm in enumerate(names) if not pats or any(p in nm for p in pats)]
-o = Oracle()
-b = o.generate(1, n, 3)
+b = nbx.uniform_bodies(n, 3, 1)
 with nbx.Context(n, 3) as c:
     c.upload(b)
     res = {v: [] for v in sel}
