@@ -79,6 +79,28 @@ int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t body_st
 int nbx_leapfrog(void* bodies, size_t n, int dim, size_t body_stride_bytes,
                  double G, double dt, int nsteps, int device, float* kernel_ms_total);
 
+/* ---- leaf-pair direct sums (the near-field step of the reference's tree codes) ------------
+ * Replaces the pointer-chasing direct sums of FMM_Parlay<D>::p2p_phase (nbody-sim-new/fmm_parlay.cpp:916-1022),
+ * of the BVH leaf loop (bvh.cpp:150-176) and of the Barnes-Hut octree's leaf term (octree.cpp:105-125): for every
+ * target leaf t and every source leaf s on t's list, every body of t sums the pair terms of every body of s.
+ *   leaf_offsets[n_leaves+1], leaf_bodies[leaf_offsets[n_leaves]]: leaf l owns the bodies (indices into `bodies`)
+ *       leaf_bodies[leaf_offsets[l] .. leaf_offsets[l+1]); a body belongs to at most one leaf; leaves may be empty.
+ *   list_offsets[n_leaves+1], list_sources[list_offsets[n_leaves]]: the source leaves of target leaf t, summed in
+ *       list order (include t itself for the leaf's own bodies, like the reference's "self interactions",
+ *       fmm_parlay.cpp:973-974).
+ *   law: per-pair rule, all of the form  G m_i m_j d / r^4  with d = p_j - p_i:
+ *       NBX_LAW_BRUTE      methods.cpp:21-37: force -= ...; pairs with r^2 < 1e-10 skipped (the brute-force law)
+ *       NBX_LAW_TREE_LEAF  octree.cpp:105-125 / bvh.cpp:150-176: force += ...; pairs with r^2 < 1e-9 skipped
+ *       NBX_LAW_FMM_P2P    fmm_parlay.cpp:992-1020: force += ...; identical positions (|d_k| <= 1e-14) skipped; for
+ *                          r^2 < 1e-10 the magnitude uses r^2 + (1e-5)^2 while the direction stays d/|d|
+ * forces_out: n x Vector<dim>, zero for bodies in no leaf.  fp32 pair terms on leaf-ordered SoA arrays, fp64 sums;
+ * every index array is validated on the host before anything is launched (NBX_ERR_INVALID).  kernel_ms optional. */
+enum { NBX_LAW_BRUTE = 0, NBX_LAW_TREE_LEAF = 1, NBX_LAW_FMM_P2P = 2 };
+int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
+                         const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
+                         const uint32_t* list_offsets, const uint32_t* list_sources,
+                         int law, double G, int device, double* forces_out, float* kernel_ms);
+
 /* ---- device-resident context ------------------------------------------------------------------
  * A context owns the targets of ONE shard of an N-body system on ONE device and a full-length
  * fp32 copy of all N sources.  n_shards = 1, shard = 0 is the single-GPU case.  With n_shards = G

@@ -7,13 +7,15 @@ through the root-level shim:  `import nbody_amd as nbx`  (or importlib with the 
   host/      C++ mirror of the reference's methods.h entry points + benchmark harness
   capi.py    ctypes binding of the C ABI (same entry-point names for Python callers / tests)
   sharding.py, dist.py   one-process-per-GPU sharding over torch.distributed (RCCL)
+  leaves.py  CSR leaf lists for the leaf-pair direct-sum entry point (tree codes' near field)
 """
 from .capi import (  # noqa: F401
     ABI, EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE,
+    LAW_BRUTE, LAW_FMM_P2P, LAW_TREE_LEAF,
     Context, NbxError, Node,
-    body_stride, brute_force_hip_n_body, device_count, leapfrog_hip_n_body, load_library, variants,
+    body_stride, brute_force_hip_n_body, device_count, leaf_pair_forces_hip, leapfrog_hip_n_body, load_library, variants,
 )
-from . import generate, sharding  # noqa: E402,F401
+from . import generate, leaves, sharding  # noqa: E402,F401
 from .generate import plummer_bodies, uniform_bodies  # noqa: E402,F401
 
 

@@ -35,6 +35,7 @@ ABI = [
     ("nbx_warmup", _i, [_i]),
     ("nbx_brute_force_forces", _i, [_vp, _sz, _i, _sz, _d, _i, _vp, _pf]),
     ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
+    ("nbx_leaf_pair_forces", _i, [_vp, _sz, _i, _sz, _vp, _vp, _sz, _vp, _vp, _i, _d, _i, _vp, _pf]),
     ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),
     ("nbx_ctx_destroy", _i, [_vp]),
     ("nbx_ctx_set_stream", _i, [_vp, _vp]),
@@ -160,6 +161,27 @@ def leapfrog_hip_n_body(bodies: np.ndarray, dt: float, nsteps: int, G: float = R
     rc = lib.nbx_leapfrog(b.ctypes.data, b.shape[0], dim, b.shape[1] * 8, G, dt, nsteps, device, ctypes.byref(ms))
     _check(lib, rc, "nbx_leapfrog")
     return ms.value
+
+
+LAW_BRUTE, LAW_TREE_LEAF, LAW_FMM_P2P = 0, 1, 2
+
+
+def leaf_pair_forces_hip(bodies: np.ndarray, leaf_offsets, leaf_bodies, list_offsets, list_sources, law: int = LAW_FMM_P2P,
+                         G: float = REFERENCE_G, device: int = 0, return_kernel_ms: bool = False):
+    """Direct (near-field) sums of the reference's tree codes over CSR leaf lists -- FMM_Parlay<D>::p2p_phase
+    (nbody-sim-new/fmm_parlay.cpp:916-1022), the BVH leaf loop (bvh.cpp:150-176), the octree leaf term
+    (octree.cpp:105-125) -- on the device; see nbx_leaf_pair_forces in include/nbody_hip.h."""
+    lib = load_library()
+    b, dim = _as_bodies(bodies)
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (leaf_offsets, leaf_bodies, list_offsets, list_sources)]
+    if arrs[0].size < 1 or arrs[2].size != arrs[0].size:
+        raise ValueError("leaf_offsets and list_offsets must both have n_leaves + 1 entries")
+    out = np.empty((b.shape[0], dim), dtype=np.float64)
+    ms = ctypes.c_float(0.0)
+    _check(lib, lib.nbx_leaf_pair_forces(b.ctypes.data, b.shape[0], dim, b.shape[1] * 8, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                         arrs[0].size - 1, arrs[2].ctypes.data, arrs[3].ctypes.data, law, G, device,
+                                         out.ctypes.data, ctypes.byref(ms)), "nbx_leaf_pair_forces")
+    return (out, ms.value) if return_kernel_ms else out
 
 
 class Context:

@@ -28,9 +28,12 @@ namespace {
 constexpr int kLeafBlock = 128;   // targets per workgroup = source bodies per LDS tile
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
-constexpr float kTreeSkipF = 1.0e-9f;    // octree.cpp:119, bvh.cpp:167
-constexpr float kSmoothF = 1.0e-10f;     // fmm_parlay.cpp:1010
-static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10, "fp32 thresholds must not round below the fp64 ones");
+constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
+constexpr float kSmoothF = 0x1.b7cdfep-34f;     // 1.00000001e-10 (fmm_parlay.cpp:1010: dist_sq < 1e-10)
+constexpr float kNormZeroF = 0x1.79ca12p-67f;   // 1.00000005e-20 (vector.h:93-97: |diff| < 1e-10 -> zero vector)
+constexpr float kSameF = 1.0e-14f;              // largest fp32 <= 1e-14 (fmm_parlay.cpp:995-1000: |d_k| > 1e-14 -> distinct)
+static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double)kNormZeroF >= 1e-20 && (double)kSameF <= 1e-14,
+              "fp32 thresholds must sit on the right side of the fp64 ones");
 
 struct TargetBlock {
     uint32_t leaf;     // target leaf
@@ -65,11 +68,11 @@ __device__ __forceinline__ void leaf_interact(float4 s, float ix, float iy, floa
         const float ri = __builtin_amdgcn_rcpf(g);
         w = s.w * ri * ri;
     } else {
-        const bool same = __builtin_fabsf(dx) <= 1e-14f && __builtin_fabsf(dy) <= 1e-14f && (D == 2 || __builtin_fabsf(dz) <= 1e-14f);
+        const bool same = __builtin_fabsf(dx) <= kSameF && __builtin_fabsf(dy) <= kSameF && (D == 2 || __builtin_fabsf(dz) <= kSameF);
         if (r2 < kSmoothF) {   // rare: smoothed magnitude, unsmoothed direction (fmm_parlay.cpp:1010-1020, vector.h:93-97)
-            const float r2s = r2 + 1.0e-10f;
+            const float r2s = r2 + 1.0e-10f;                                                   // epsilon^2, epsilon = 1e-5
             const float mag = s.w * __builtin_amdgcn_rcpf(r2s) * __builtin_amdgcn_rsqf(r2s);   // m / (r2s * sqrt(r2s))
-            const float inv = (r2 < 1.0e-20f) ? 0.0f : __builtin_amdgcn_rsqf(r2);               // normalized(): 0 below 1e-10
+            const float inv = (r2 < kNormZeroF) ? 0.0f : __builtin_amdgcn_rsqf(r2);               // normalized(): 0 below 1e-10
             w = same ? 0.0f : mag * inv;
         } else {
             const float ri = __builtin_amdgcn_rcpf(r2);
@@ -108,11 +111,8 @@ __global__ __launch_bounds__(kLeafBlock) void leaf_pair_kernel(LeafArgs a) {
             tile[tid] = v;
             __syncthreads();
             float ax = 0.f, ay = 0.f, az = 0.f;
-            if (LAW == NBX_LAW_BRUTE && s == tb.leaf) {
-                // own leaf under the brute-force law: methods.cpp:113 skips i == j by INDEX (a duplicate at the
-                // same position is skipped by the r^2 rule anyway; the index rule matters for r^2 >= 1e-10 only,
-                // which a body never has with itself) -- nothing to do beyond the r^2 rule.
-            }
+            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
+            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
             for (uint32_t j = 0; j < cnt; ++j) leaf_interact<D, LAW>(tile[j], ix, iy, iz, ax, ay, az);
             ox += (double)ax; oy += (double)ay; oz += (double)az;
         }

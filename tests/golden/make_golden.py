@@ -10,6 +10,9 @@ see oracle/ref_driver.cpp) -- data, not source.  Files are numpy .npz (no pickle
                                  and the same for the fp32-rounded inputs the device path consumes
   traj_D{2,3}_N64.npz            5 x { seq forces; update_body_velocities; update_body_positions }
   kat.npz                        known-answer cases: two-body, coincident bodies, r^2 guard either side
+  octree_direct_D{2,3}_N512.npz  (python tests/golden/make_golden.py octree) fp32-representable bodies and the forces of
+                                 the reference's Barnes-Hut octree walked with theta = 0 (octree.cpp:105-125 reached for
+                                 every pair): the tree codes' attractive leaf law, SURVEY 8f-4
 """
 import os
 import subprocess
@@ -32,10 +35,26 @@ def round_f32(b, dim):
     return r
 
 
+def octree(ref):
+    for dim in (2, 3):
+        n = 512
+        b = round_f32(ref.generate(SEED + 2, n, dim), dim)
+        b[11, :dim] = (50.0, 60.0, 70.0)[:dim]    # small coordinates: fp32 spacing 3.8e-6, so the offset below survives
+        b[10, :dim] = b[11, :dim]
+        b[10, 0] += 2.0e-5                        # r^2 = 3.6e-10: below the leaf law's 1e-9 skip, above the brute-force law's 1e-10
+        b = round_f32(b, dim)
+        assert 1e-10 < ((b[10, :dim] - b[11, :dim]) ** 2).sum() < 1e-9
+        np.savez_compressed(os.path.join(HERE, f"octree_direct_D{dim}_N{n}.npz"), bodies_f32=b, G=np.float64(ref.G()),
+                            forces_octree_theta0=ref.octree_direct_forces(b), forces_brute_seq=ref.brute_force(0, b))
+
+
 def main():
     subprocess.check_call([os.path.join(ROOT, "oracle", "build_ref.sh")])
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "octree":
+        octree(ref)
+        return
     assert ref.sizeof_body(3) == 56 and ref.sizeof_body(2) == 40
     for dim in (2, 3):
         for n in (2, 3, 64, 1024):
@@ -79,6 +98,7 @@ def main():
     ref.update_body_positions(s, 1.0)
     out["two_after_step_dt1"] = s
     np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
+    octree(ref)
     print("golden vectors written to", HERE)
 
 

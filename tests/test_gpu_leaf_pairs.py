@@ -1,0 +1,128 @@
+"""GPU: SURVEY 8(f-4) -- nbx_leaf_pair_forces (csrc/leaf_pair_kernel.hip, through the C ABI) against the oracle's
+restatement of the reference's leaf direct sums (fmm_parlay.cpp:992-1020, bvh.cpp:150-176, octree.cpp:105-125) and
+against the committed outputs of the reference's own octree walked with theta = 0.  Same stated fp32 tolerance as the
+brute-force path (oracle_lib.TOL_*)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle_lib import assert_force_parity
+
+pytestmark = pytest.mark.gpu
+LAWS = ((0, "brute"), (1, "tree_leaf"), (2, "fmm_p2p"))
+
+
+def _check(nbx, oracle, b, leaves, law, what):
+    f = nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=oracle.G)
+    ref = oracle.leaf_pair_forces(b, leaves, law)
+    S = oracle.leaf_pair_magnitude_sums(b, leaves, law)
+    assert f.shape == ref.shape and np.isfinite(f).all()
+    live = S > 0
+    assert not f[~live].any(), f"{what}: bodies without any counted pair must get exactly zero"
+    if live.any():
+        assert_force_parity(f[live], ref[live], S[live], what)
+    return f, ref
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+@pytest.mark.parametrize("law,name", LAWS)
+def test_grid_leaves_against_oracle(nbx, oracle, dim, law, name):
+    n = 20000
+    b = oracle.round_inputs_to_f32(oracle.generate(50 + dim, n, dim))
+    leaves = nbx.leaves.uniform_grid_leaves(b, dim, 3 if dim == 3 else 4)
+    f, ref = _check(nbx, oracle, b, leaves, law, f"grid leaves, law {name}, D={dim}")
+    if law != 0:                                # the tree codes' laws are the brute-force law with the sign flipped
+        f0 = nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_BRUTE, G=oracle.G)
+        assert np.abs(f + f0).max() <= 1e-4 * np.abs(f0).max()
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+def test_reference_octree_golden(nbx, oracle, dim):
+    """Committed output of the reference's octree (theta = 0 walk): every pair through octree.cpp:105-125."""
+    g = golden(f"octree_direct_D{dim}_N512.npz")
+    b = np.ascontiguousarray(g["bodies_f32"])
+    one = (np.array([0, 512]), np.arange(512), np.array([0, 1]), np.array([0]))
+    f = nbx.leaf_pair_forces_hip(b, *one, law=nbx.LAW_TREE_LEAF, G=float(g["G"]))
+    assert_force_parity(f, g["forces_octree_theta0"], oracle.leaf_pair_magnitude_sums(b, one, 1), f"octree golden D={dim}")
+    assert np.allclose(f[10], g["forces_octree_theta0"][10], rtol=1e-4, atol=0)      # partner at r^2 = 3.6e-10: skipped
+    fb = nbx.leaf_pair_forces_hip(b, *one, law=nbx.LAW_BRUTE, G=float(g["G"]))
+    assert_force_parity(fb, g["forces_brute_seq"], oracle.force_magnitude_sums(b), f"brute law over one leaf D={dim}")
+    assert np.allclose(fb[10], g["forces_brute_seq"][10], rtol=1e-4, atol=0)         # ... and counted by the brute-force law
+
+
+def test_all_pairs_lists_equal_the_brute_force_path(nbx, oracle):
+    """Every leaf on every list: the leaf kernel under the brute-force law must agree with the all-pairs kernel."""
+    n, dim = 6000, 3
+    b = oracle.round_inputs_to_f32(oracle.generate(61, n, dim))
+    A = nbx.leaves.all_pairs_leaves(n, 100)                        # ragged last leaf, leaves below one tile
+    f, ref = _check(nbx, oracle, b, A, 0, "all-pairs lists")
+    assert_force_parity(f, oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "leaf kernel vs sequential reference")
+    assert_force_parity(nbx.brute_force_hip_n_body(b, oracle.G), ref, oracle.force_magnitude_sums(b), "brute-force kernel vs leaf oracle")
+
+
+def test_ragged_structure_and_close_pairs(nbx, oracle):
+    """Empty leaves, a leaf larger than one 128-body tile, leaves off every list, an empty list, repeated list entries,
+    bodies in no leaf; identical positions, sub-threshold and just-above-threshold pairs for every law."""
+    dim, n = 3, 1000
+    b = oracle.generate(70, n, dim)
+    b[:, :3] = b[:, :3] / 1.0e5                                     # box of 100: close pairs are representable in fp32
+    b[1, :3] = b[0, :3]                                            # identical positions
+    b[3, :3] = b[2, :3]; b[3, 0] += 4.0e-6                          # r^2 = 1.6e-11: < 1e-10 (brute: skip, tree: skip, fmm: smoothed)
+    b[5, :3] = b[4, :3]; b[5, 1] += 2.0e-5                          # r^2 = 4e-10: brute counts, tree skips, fmm counts unsmoothed
+    b[7, :3] = b[6, :3]; b[7, 2] += 4.0e-5                          # r^2 = 1.6e-9: everyone counts
+    b = oracle.round_inputs_to_f32(b)
+    sizes = [300, 0, 1, 129, 0, 64, 200, 256]                       # 950 of 1000 bodies; 50 in no leaf
+    lo = np.concatenate([[0], np.cumsum(sizes)])
+    lb = np.random.default_rng(1).permutation(n)[:lo[-1]]
+    lb[:8] = np.arange(8)                                           # the planted pairs share leaf 0 ...
+    rest = np.setdiff1d(np.arange(8, n), [])
+    lb[8:] = np.random.default_rng(2).permutation(rest)[:lo[-1] - 8]
+    lists = [[0, 3, 0], [2], [], [0, 1, 2, 3, 4, 5, 6, 7], [0], [5], [7, 6], [3]]   # repeated entry, empty list, empty sources
+    so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    ss = np.array([s for l in lists for s in l])
+    leaves = (lo, lb, so, ss)
+    for law, name in LAWS:
+        f, ref = _check(nbx, oracle, b, leaves, law, f"ragged, law {name}")
+        out = np.setdiff1d(np.arange(n), lb)
+        assert not f[out].any()
+        for i in range(8):                                          # the planted bodies, dominated by their partner where counted
+            assert np.linalg.norm(f[i] - ref[i]) <= 2e-5 * max(np.linalg.norm(ref[i]), 1e-300), (name, i, f[i], ref[i])
+    f0 = oracle.leaf_pair_forces(b, leaves, 0); f1 = oracle.leaf_pair_forces(b, leaves, 1); f2 = oracle.leaf_pair_forces(b, leaves, 2)
+    assert np.abs(f2[2]).max() > 1e3 * np.abs(f0[2]).max()          # only the FMM law keeps the 4e-6 pair (smoothed)
+    assert np.abs(f0[4]).max() > 1e3 * np.abs(f1[4]).max()          # the tree-leaf law drops the 2e-5 pair
+
+
+def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
+    b = oracle.generate(1, 10, 3)
+    ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
+    nbx.leaf_pair_forces_hip(b, *ok)
+    bad = [
+        (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 2])),      # source leaf out of range
+        (np.array([0, 5, 10]), np.r_[np.arange(9), 10], np.array([0, 1, 2]), np.array([0, 1])),   # body out of range
+        (np.array([0, 5, 10]), np.r_[np.arange(9), 0], np.array([0, 1, 2]), np.array([0, 1])),    # body in two leaves
+        (np.array([0, 6, 5]), np.arange(6), np.array([0, 1, 2]), np.array([0, 1])),        # decreasing offsets
+        (np.array([1, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1])),      # offsets not starting at 0
+    ]
+    for leaves in bad:
+        with pytest.raises(nbx.NbxError):
+            nbx.leaf_pair_forces_hip(b, *leaves)
+    with pytest.raises(nbx.NbxError):
+        nbx.leaf_pair_forces_hip(b, *ok, law=7)
+    assert nbx.leaf_pair_forces_hip(np.zeros((0, 7)), np.array([0]), np.zeros(0), np.array([0]), np.zeros(0)).shape == (0, 3)
+
+
+def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
+    """N = 2^20, leaves of <= ~100 bodies (FMM_MAX_BODIES_PER_LEAF, methods.h:26), 27-cell lists: sampled bodies vs the
+    oracle and the kernel's own time."""
+    n, dim = 1 << 20, 3
+    b = oracle.round_inputs_to_f32(oracle.generate(5, n, dim))
+    leaves = nbx.leaves.uniform_grid_leaves(b, dim, 5)              # 32^3 cells, 32 bodies per leaf on average
+    f, ms = nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_FMM_P2P, G=oracle.G, return_kernel_ms=True)
+    ref = oracle.leaf_pair_forces(b, leaves, 2)
+    S = oracle.leaf_pair_magnitude_sums(b, leaves, 2)
+    rows = np.random.default_rng(0).integers(0, n, 4096)
+    assert_force_parity(f[rows], ref[rows], S[rows], "FMM-like leaves, sampled bodies")
+    lo, _, so, ss = leaves
+    sizes = np.diff(lo).astype(np.int64)
+    pairs = int(sum(sizes[t] * sizes[ss[so[t]:so[t + 1]]].sum() for t in range(sizes.size)))
+    print(f"\nleaf-pair kernel: N={n}, {sizes.size} leaves (max {sizes.max()}), {pairs:.3e} pair terms in {ms:.2f} ms = {pairs / ms * 1e3:.3e} pairs/s")
