@@ -28,6 +28,7 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 FLOP_PER_INTERACTION = 20          # SURVEY 8d convention (3 sub, 5 r^2, rcp, 3 mul, 6 fma-acc, 2 guard)
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = FP32 matrix
 HBM_PEAK_GBPS = 8000.0
+PROFILE_ROUND = "r2"               # profiles/<round>/pmc_force_kernel.json: the committed PMC passes of this command
 
 
 def host_facts():
@@ -282,21 +283,28 @@ def main():
                                  "peak_GBps": HBM_PEAK_GBPS}},
         }
     if rank == 0 and world == 1 and N == 1 << 20 and args.dim == 3:
-        # HBM traffic of the force kernel per launch: not measurable from inside the process; taken from the
-        # committed rocprofv3 --pmc passes of this same command (tools/profile_bench.sh -> profiles/), if they
-        # are for the variant that just ran.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads (guide: x2
+        # HBM traffic of the force kernel per launch: PMC counters cannot be read from inside the process; they come from
+        # the committed rocprofv3 --pmc passes of this same command (tools/profile_bench.sh -> tools/summarize_prof.py ->
+        # profiles/<round>/pmc_force_kernel.json), and only if that profile is of the kernel that just ran -- otherwise the
+        # field stays null and says why.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads (guide: the x2 correction
         # applies to 16-byte streaming loads), so the raw sum is reported.
+        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1>",
+                     "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>"}
+        prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
         try:
-            prof = os.path.join(ROOT, "profiles", "r1c", "pmc_force_kernel.json")
-            with open(prof) as f:
+            with open(os.path.join(ROOT, prof)) as f:
                 pmc = json.load(f)
-            if "accel_fast_pk_kernel<3, 4, 3, 4, 1>" in pmc["pmc_fetch"]["kernel"]["Kernel_Name"] and variant_name.startswith("fastpks_t8_w3_u4"):
+            profiled = pmc["pmc_fetch"]["kernel"]["Kernel_Name"]
+            if kernel_of.get(variant_name, "?") in profiled and profiled == pmc["pmc_write"]["kernel"]["Kernel_Name"]:
                 fetch_kb = pmc["pmc_fetch"]["per_launch_mean"]["FETCH_SIZE"]
                 write_kb = pmc["pmc_write"]["per_launch_mean"]["WRITE_SIZE"]
                 result["roofline"]["traffic"] = (fetch_kb + write_kb) * 1024.0
-                result["roofline"]["traffic_source"] = "profiles/r1c/pmc_force_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; raw, per launch)"
-        except Exception:
-            pass
+                result["roofline"]["traffic_source"] = (f"{prof}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command and this kernel "
+                                                        f"({fetch_kb / 1024:.0f} + {write_kb / 1024:.0f} MiB per launch, raw)")
+            else:
+                result["roofline"]["traffic_source"] = f"stale: {prof} is a profile of '{profiled}', the run used variant {variant_name}"
+        except Exception as e:
+            result["roofline"]["traffic_source"] = f"no PMC profile available ({prof}: {e.__class__.__name__})"
     if rank == 0 and world > 1:
         # self-description of the N > 1 path (never executed on hardware before the driver's scaling run)
         result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0

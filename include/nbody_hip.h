@@ -185,6 +185,13 @@ int nbx_ctx_synchronize(nbx_ctx* ctx);
  * result keeps the reference's skip semantics; when their preconditions fail (a mass above 1e10, or more than
  * 1/8 of the shard in the candidate set) the library substitutes the guarded default. */
 int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
+/* EXTENSION (not in the reference: its brute force is unsoftened): Plummer softening of the pair law,
+ *   a_i = sum_{j != i} m_j (p_j - p_i) / (r^2 + epsilon^2)^2 ,   U = sum_{i<j} G m_i m_j / (2 (r^2 + epsilon^2)),
+ * every pair counted (no r^2 < 1e-10 skip; a body never acts on itself).  epsilon = 0 (default) is the reference law.
+ * Same kernel, same speed: epsilon^2 replaces the fast kernel's r^2 bias and no close-set bookkeeping is needed.
+ * epsilon must be 0 or in [1e-6, 1e15], and max|m| / epsilon^4 must be finite in fp32 (checked at the next force
+ * evaluation).  Applies to compute_accel / step / energy of this context. */
+int nbx_ctx_set_softening(nbx_ctx* ctx, double epsilon);
 /* The variant and slice count the next force evaluation will use (after upload). */
 int nbx_ctx_effective_tuning(nbx_ctx* ctx, int* variant, int* source_splits);
 int nbx_num_variants(void);
@@ -219,6 +226,7 @@ int nbx_node_upload_bodies(nbx_node* node, const void* bodies, size_t body_strid
  * exchange delivered every chunk everywhere).  Synchronises; leaves the buffers whole when it passes. */
 int nbx_node_verify_exchange(nbx_node* node, size_t* mismatches);
 int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
+int nbx_node_set_softening(nbx_node* node, double epsilon);   /* nbx_ctx_set_softening on every rank */
 /* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
 /* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */

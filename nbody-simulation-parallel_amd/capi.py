@@ -52,6 +52,7 @@ ABI = [
     ("nbx_ctx_energy", _i, [_vp, _d, _pd, _pd]),
     ("nbx_ctx_synchronize", _i, [_vp]),
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
+    ("nbx_ctx_set_softening", _i, [_vp, _d]),
     ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
     ("nbx_num_variants", _i, []),
     ("nbx_variant_name", _c.c_char_p, [_i]),
@@ -63,6 +64,7 @@ ABI = [
     ("nbx_node_upload_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_node_verify_exchange", _i, [_vp, _c.POINTER(_sz)]),
     ("nbx_node_set_tuning", _i, [_vp, _i, _i]),
+    ("nbx_node_set_softening", _i, [_vp, _d]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
     ("nbx_node_synchronize", _i, [_vp]),
@@ -231,6 +233,10 @@ class Context:
     def set_tuning(self, source_splits: int = 0, variant: int = -1):
         self._ck(self.lib.nbx_ctx_set_tuning(self.h, source_splits, variant), "nbx_ctx_set_tuning")
 
+    def set_softening(self, epsilon: float):
+        """Extension: Plummer-softened pair law (epsilon = 0 restores the reference's unsoftened law)."""
+        self._ck(self.lib.nbx_ctx_set_softening(self.h, float(epsilon)), "nbx_ctx_set_softening")
+
     def effective_tuning(self) -> Tuple[str, int]:
         v, s = ctypes.c_int(0), ctypes.c_int(0)
         self._ck(self.lib.nbx_ctx_effective_tuning(self.h, ctypes.byref(v), ctypes.byref(s)), "nbx_ctx_effective_tuning")
@@ -341,6 +347,9 @@ class Node:
 
     def set_tuning(self, source_splits: int = 0, variant: int = -1):
         self._ck(self.lib.nbx_node_set_tuning(self.h, source_splits, variant), "nbx_node_set_tuning")
+
+    def set_softening(self, epsilon: float):
+        self._ck(self.lib.nbx_node_set_softening(self.h, float(epsilon)), "nbx_node_set_softening")
 
     def forces(self, G: float = REFERENCE_G) -> np.ndarray:
         out = np.empty((self.n_total, self.dim), dtype=np.float64)

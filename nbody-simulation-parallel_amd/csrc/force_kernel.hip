@@ -64,7 +64,8 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
 // Two-vector arithmetic for PAIRS target pairs at once (the two halves of a 64-bit register = two targets),
 // written stage by stage so that the PAIRS dependency chains are interleaved in program order (each v_pk
 // result is consumed PAIRS instructions later).  Per source and target PAIR, D = 3:
-//   ONE_RCP = 0:  v_pk_add x3, v_pk_fma x3 (r^2 + kTiny), v_rcp x2, v_pk_mul x2, v_pk_fma x3      = 13 VALU
+//   ONE_RCP = 0:  v_pk_add x3, v_pk_fma x3 (r^2 + bias), v_rcp x2, v_pk_mul x2, v_pk_fma x3       = 13 VALU
+//                 bias = kTiny for the reference law (see nbx_internal.h), = epsilon^2 for the softened law
 //   ONE_RCP = 1:  the two reciprocals come from ONE v_rcp_f32 of the product: W = 1/(r2a*r2b),
 //                 (1/r2a, 1/r2b) = W * (r2b, r2a)  -- v_mul, v_rcp, v_pk_mul(op_sel swap) instead of v_rcp x2
 //                 (3.45 ns -> 3.0 ns of the 27.7 ns body, tools/ubench_valu.hip).  r2a*r2b must stay finite:
@@ -72,7 +73,7 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
 template <int D, int PAIRS, int ONE_RCP>
 __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, float sm, const f2 (&ix)[PAIRS],
                                                  const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
-                                                 f2 (&ay)[PAIRS], f2 (&az)[PAIRS]) {
+                                                 f2 (&ay)[PAIRS], f2 (&az)[PAIRS], const f2 bias) {
     f2 dx[PAIRS], dy[PAIRS], dz[PAIRS], r2[PAIRS], w[PAIRS];
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) dx[q] = f2{sx, sx} - ix[q];
@@ -81,7 +82,7 @@ __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) dz[q] = (D == 3) ? f2{sz, sz} - iz[q] : f2{0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dx[q], dx[q], f2{kTiny, kTiny});
+    for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dx[q], dx[q], bias);
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) r2[q] = __builtin_elementwise_fma(dy[q], dy[q], r2[q]);
     if (D == 3) {
@@ -234,14 +235,18 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // Flagged (bad) targets are neither stored nor trusted; the launch's extra workgroups
 // (blockIdx.x < close_blocks) evaluate them with the guard (close_set_path below).
 // -------------------------------------------------------------------------------------------------
-template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP>
+// SOFT = 1: Plummer-softened law  a_i = sum_j m_j d / (r^2 + eps^2)^2  (nbx_ctx_set_softening; an extension -- the
+// reference's brute force has no softening).  The bias of r^2 is then eps^2 itself, every pair is counted,
+// and there is no close set: close_blocks = 0, bad_flag is not read.
+template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
-    if (blockIdx.x < a.close_blocks) {  // the launch's extra workgroups: guarded evaluation of the close set
+    if (!SOFT && blockIdx.x < a.close_blocks) {  // the launch's extra workgroups: guarded evaluation of the close set
         close_set_path<D>(a, tile);
         return;
     }
+    const f2 bias = SOFT ? f2{a.eps2, a.eps2} : f2{kTiny, kTiny};
     const unsigned tid = threadIdx.x;
     const unsigned tgt0 = (blockIdx.x - a.close_blocks) * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll UNROLL
         for (int j = 0; j < kTile; ++j) {
             const float4 s = cur[j];
-            interact2_staged<D, PAIRS, ONE_RCP>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
+            interact2_staged<D, PAIRS, ONE_RCP>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az, bias);
         }
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned i = tgt0 + (2 * q + h) * 256u;
-            if (!a.bad_flag[i])  // flagged targets belong to close_set_path + scatter_close_kernel
+            if (SOFT || !a.bad_flag[i])  // flagged targets belong to close_set_path + scatter_close_kernel
                 store_result<D>(a, out, i, h ? ox[q].y : ox[q].x, h ? oy[q].y : oy[q].x, h ? oz[q].y : oz[q].x);
         }
     }
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
 // Same tiling as the exact force kernel, two targets per lane, fp64 second level; 9 VALU per pair.
 // Writes phi[slice][i] (fp32), summed over slices in fp64 by export_energy_kernel.
 // -------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int SOFT>
 __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     constexpr int TPL = 2;
     __shared__ float4 tile[2][kTile];
@@ -493,6 +498,10 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     for (; t < t_end; ++t) {
         tile[buf][tid] = nxt;
         __syncthreads();
+        // softened law: a body's own entry (r^2 = 0, weight m/eps^2) is excluded by INDEX -- the tile that holds this
+        // workgroup's q-th targets is tile (blockIdx.x*TPL + q) of the target chunk, entry tid (workgroup-uniform test)
+        const unsigned rel = w.k - blockIdx.x * TPL;
+        const bool own_tile = SOFT && w.chunk(a.chunk_first, a.chunk_skip) == a.tgt_chunk && rel < (unsigned)TPL;
         if (t + 1 < t_end) {
             w.next(a.tiles_per_chunk);
             nxt = load_source<D>(a, w, tid);
@@ -501,16 +510,30 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 #pragma unroll
         for (int q = 0; q < TPL; ++q) p[q] = 0.0f;
         const float4* __restrict__ cur = tile[buf];
-#pragma unroll 8
-        for (int j = 0; j < kTile; ++j) {
-            const float4 s = cur[j];
+        if (own_tile) {
+            for (int j = 0; j < kTile; ++j) {
+                const float4 s = cur[j];
 #pragma unroll
-            for (int q = 0; q < TPL; ++q) {
-                const float dx = s.x - ix[q], dy = s.y - iy[q];
-                float r2 = __builtin_fmaf(dy, dy, dx * dx);
-                if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
-                const float r2g = (r2 < kR2SkipF) ? __builtin_inff() : r2;
-                p[q] = __builtin_fmaf(s.w, __builtin_amdgcn_rcpf(r2g), p[q]);
+                for (int q = 0; q < TPL; ++q) {
+                    const float dx = s.x - ix[q], dy = s.y - iy[q];
+                    float r2 = __builtin_fmaf(dy, dy, dx * dx);
+                    if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
+                    const float wgt = ((unsigned)q == rel && (unsigned)j == tid) ? 0.0f : __builtin_amdgcn_rcpf(r2 + a.eps2);
+                    p[q] = __builtin_fmaf(s.w, wgt, p[q]);
+                }
+            }
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < kTile; ++j) {
+                const float4 s = cur[j];
+#pragma unroll
+                for (int q = 0; q < TPL; ++q) {
+                    const float dx = s.x - ix[q], dy = s.y - iy[q];
+                    float r2 = __builtin_fmaf(dy, dy, dx * dx);
+                    if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
+                    const float r2g = SOFT ? r2 + a.eps2 : ((r2 < kR2SkipF) ? __builtin_inff() : r2);
+                    p[q] = __builtin_fmaf(s.w, __builtin_amdgcn_rcpf(r2g), p[q]);
+                }
             }
         }
 #pragma unroll
@@ -523,9 +546,10 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 }
 
 // ---- variant table: the default fast kernel, its one-reciprocal comparator, and the exact (guarded) kernel ------
-#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0
+#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0, nullptr, nullptr
 #define NBX_FAST(PAIRS, WAVES, UNROLL, ONE_RCP) \
-    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP>, 1, 256, ONE_RCP
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP>, 1, 256, ONE_RCP, \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 1>
 
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
@@ -546,7 +570,8 @@ CloseKernels close_kernels() {
     k.classify_src[0] = classify_sources_kernel<2>; k.classify_src[1] = classify_sources_kernel<3>;
     k.refine[0] = refine_close_kernel<2>;     k.refine[1] = refine_close_kernel<3>;
     k.scatter[0] = scatter_close_kernel<2>;   k.scatter[1] = scatter_close_kernel<3>;
-    k.potential[0] = potential_kernel<2>;     k.potential[1] = potential_kernel<3>;
+    k.potential[0] = potential_kernel<2, 0>;  k.potential[1] = potential_kernel<3, 0>;
+    k.potential_soft[0] = potential_kernel<2, 1>; k.potential_soft[1] = potential_kernel<3, 1>;
     return k;
 }
 

@@ -81,20 +81,23 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.src_stride = (unsigned)L.n_chunks * L.pad;
     a.n_total = (unsigned)L.n_total;
     a.shard_len = (unsigned)L.shard_len;
+    a.eps2 = L.eps2;
+    const bool soft = L.eps2 > 0.0f;
+    if (soft && !(V.fast && V.soft2 && V.soft3)) return hipErrorInvalidValue;   // softened law: fast kernels only
     // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
-    if (V.fast && (!L.cand_list || !L.cand_pos || !L.bad_list || !L.bad_flag || !L.counters || !L.close_acc || !L.src_cand_pos)) return hipErrorInvalidValue;
-    if (V.fast && (L.n_chunks < 1 || L.n_total > ((size_t)1 << 31) || (size_t)L.n_chunks * L.pad > 0xffffffffull ||
+    if (V.fast && !soft && (!L.cand_list || !L.cand_pos || !L.bad_list || !L.bad_flag || !L.counters || !L.close_acc || !L.src_cand_pos)) return hipErrorInvalidValue;
+    if (V.fast && !soft && (L.n_chunks < 1 || L.n_total > ((size_t)1 << 31) || (size_t)L.n_chunks * L.pad > 0xffffffffull ||
                    L.chunk_first < 0 || L.chunk_first + L.vchunks + (L.chunk_skip != INT_MAX ? 1 : 0) > L.n_chunks))
         return hipErrorInvalidValue;
     if (V.max_tiles_per_slice > 0 && a.tiles_per_split > (unsigned)V.max_tiles_per_slice) return hipErrorInvalidValue;
 
-    a.close_blocks = V.fast ? (unsigned)kCloseBlocksX : 0u;
+    a.close_blocks = (V.fast && !soft) ? (unsigned)kCloseBlocksX : 0u;
     hipError_t e = hipSuccess;
     dim3 block(256, 1, 1);
     const int di = dim - 2;
-    if (V.fast) {
+    if (V.fast && !soft) {
         // Candidate targets: a property of the own chunk's positions (rebuilt after every position update).
         if (!(L.tgt_cand_valid && *L.tgt_cand_valid)) {
             if ((e = hipMemsetAsync(L.counters, 0, sizeof(unsigned), stream)) != hipSuccess) return e;
@@ -121,11 +124,11 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     }
     dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL((dim == 3) ? V.k3 : V.k2, grid, block, 0, stream, a);
+    hipLaunchKernelGGL(soft ? ((dim == 3) ? V.soft3 : V.soft2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;
-    if (!V.fast) return hipSuccess;
+    if (!V.fast || soft) return hipSuccess;
     hipLaunchKernelGGL(table().ck.scatter[di], dim3(64, 1, 1), block, 0, stream, a);
     return hipGetLastError();
 }
@@ -146,7 +149,8 @@ hipError_t launch_potential(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.chunk_first = L.chunk_first;
     a.chunk_skip = L.chunk_skip;
     a.splits = L.splits;
-    hipLaunchKernelGGL(table().ck.potential[dim - 2], dim3(L.pad / 512u, (unsigned)L.splits, 1), dim3(256, 1, 1), 0, stream, a);
+    a.eps2 = L.eps2;
+    hipLaunchKernelGGL(L.eps2 > 0.0f ? table().ck.potential_soft[dim - 2] : table().ck.potential[dim - 2], dim3(L.pad / 512u, (unsigned)L.splits, 1), dim3(256, 1, 1), 0, stream, a);
     return hipGetLastError();
 }
 

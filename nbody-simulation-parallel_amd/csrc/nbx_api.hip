@@ -66,6 +66,11 @@ int ensure_stage(nbx_ctx* c, size_t bytes) {
 // the fast path's preconditions do not hold for this context.
 int effective_variant(const nbx_ctx* c) {
     int v = c->variant_req >= 0 ? c->variant_req : default_variant();
+    if (c->softening > 0.0) {  // softened law: the fast kernels with bias = eps^2; no close set, no guarded twin
+        if (!variant_is_fast(v)) v = default_variant();
+        if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
+        return v;
+    }
     if (variant_is_fast(v) && c->force_exact) v = default_exact_variant();
     else if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
     return v;
@@ -309,6 +314,7 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
                 if (cm < (double)kCloseCoord) ++close;
             }
         }
+        c->mass_max = mmax;
         c->force_exact = !(mmax <= kFastMaxMass) || close * 8 > c->count;
         c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
     }
@@ -336,6 +342,17 @@ int nbx_ctx_set_tuning(nbx_ctx* c, int source_splits, int variant) {
     if (c->splits_user) c->splits = source_splits;
     c->variant_req = variant;
     c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_set_softening(nbx_ctx* c, double epsilon) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    // eps^2 takes the place of the kTiny bias of r^2 in the fast kernels; below ~1e-6 it would be lost next to fp32
+    // pair terms of the reference's coordinate range, and 1/eps^4 must stay far from the fp32 range limits
+    if (!(epsilon == 0.0 || (epsilon >= 1.0e-6 && epsilon <= 1.0e15))) return fail(NBX_ERR_INVALID, "softening must be 0 or in [1e-6, 1e15]");
+    c->softening = epsilon;
+    c->have_accel = false;
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     return NBX_OK;
 }
 
@@ -371,6 +388,9 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.n_total = c->n_total; L.shard_len = c->shard_len; L.n_chunks = c->n_shards;
     L.pass = which; L.cacheable = (c->n_shards == 1 || which == NBX_SRC_LOCAL) ? 1 : 0;
     L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
+    L.eps2 = (float)(c->softening * c->softening);
+    if (c->softening > 0.0 && !(c->mass_max / ((double)L.eps2 * (double)L.eps2) < 1.0e38))
+        return fail(NBX_ERR_INVALID, "softening too small for these masses: m / eps^4 must stay finite in fp32");
     L.chunk_skip = INT_MAX; L.accumulate = 0;
     if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
@@ -410,7 +430,7 @@ namespace {
 // about capture is unavailable; the caller then steps eagerly.
 bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
-        c->graph_splits == c->splits && c->graph_stream == c->stream)
+        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening)
         return true;
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -425,6 +445,7 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     const hipError_t ei = hipGraphInstantiate(&c->step_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
+    c->graph_eps = c->softening;
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }
@@ -543,6 +564,7 @@ int nbx_ctx_energy(nbx_ctx* c, double G, double* kinetic, double* potential) {
     AccelLaunch L = {};
     L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->phi; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.chunk_first = 0; L.vchunks = c->n_shards; L.chunk_skip = INT_MAX; L.splits = kPhiSlices;
+    L.eps2 = (float)(c->softening * c->softening);
     HIP_TRY(launch_potential(c->dim, L, c->stream));
     const size_t bytes = 2 * c->count * sizeof(double);
     rc = ensure_stage(c, bytes ? bytes : 8);

@@ -85,6 +85,7 @@ struct AccelLaunch {
     int cacheable;            // the pass's sources change only through this context (single shard, or LOCAL)
     int* tgt_cand_valid;      // host flag owned by the context: cand_list matches the own chunk's positions
     int* bad_list_pass;       // host flag owned by the context: pass whose bad list is current (-1: none)
+    float eps2;               // > 0: softened law (fast variants only; no close-set pipeline)
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -112,6 +113,7 @@ struct KArgs {
     float* __restrict__ src_cand_pos;
     unsigned src_stride;       // floats between the coordinate planes of src_cand_pos (= n_chunks * pad)
     unsigned n_total, shard_len;
+    float eps2;                // softened law: epsilon^2 (0: the reference law)
 };
 
 struct KernelVariant {
@@ -122,10 +124,12 @@ struct KernelVariant {
     int fast;             // 1: unguarded fast kernel + close-set pipeline (exact overall)
     int max_tiles_per_slice;  // > 0: the kernel's fp32 second-level sums want at most this many tiles per slice
     int needs_extent;     // 1: only valid while every |coordinate| <= kOneRcpMaxCoord (one-reciprocal kernel)
+    void (*soft2)(KArgs); // softened-law build of the same kernel (null: none), D = 2 / 3
+    void (*soft3)(KArgs);
 };
 // force_kernel.hip
 const KernelVariant* kernel_variants(int* count);
-struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); };  // [0]: D=2, [1]: D=3
+struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
 // force_launch.hip

@@ -331,6 +331,15 @@ int nbx_node_set_tuning(nbx_node* nd, int source_splits, int variant) {
     return NBX_OK;
 }
 
+int nbx_node_set_softening(nbx_node* nd, double epsilon) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        int rc = nbx_ctx_set_softening(k.ctx, epsilon);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
 int nbx_node_compute_forces(nbx_node* nd, double G, double* forces_out) {
     if (!nd || (!forces_out && nd->n_total)) return fail(NBX_ERR_INVALID, "null argument");
     if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");

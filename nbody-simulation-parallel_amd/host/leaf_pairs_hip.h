@@ -1,0 +1,45 @@
+// leaf_pairs_hip.h -- host-side mirror of the tree codes' direct (near-field) sums, backed by nbx_leaf_pair_forces
+// (include/nbody_hip.h).  In the reference this step is FMM_Parlay<D>::p2p_phase(forces, bodies)
+// (nbody-sim-new/fmm_parlay.cpp:916-1022, tree held by the object), the BVH leaf loop (bvh.cpp:150-176) and the
+// octree leaf term (octree.cpp:105-125); here the tree is handed over as CSR leaf lists so that any tree can feed it.
+#ifndef NBODY_AMD_LEAF_PAIRS_HIP_H
+#define NBODY_AMD_LEAF_PAIRS_HIP_H
+
+#include <cstdint>
+#include <vector>
+
+#if __has_include("nbody_types.h")
+#include "nbody_types.h"
+#else
+#include "body.h"
+#include "vector.h"
+#endif
+
+// leaf l owns bodies leaf_bodies[leaf_offsets[l] .. leaf_offsets[l+1]); target leaf t sums over the source leaves
+// list_sources[list_offsets[t] .. list_offsets[t+1]) (own leaf included explicitly, fmm_parlay.cpp:973-974).
+struct LeafLists {
+    std::vector<std::uint32_t> leaf_offsets{0}, leaf_bodies, list_offsets{0}, list_sources;
+    std::size_t leaves() const { return leaf_offsets.size() - 1; }
+};
+
+enum class LeafLaw : int {
+    Brute = 0,     // methods.cpp:21-37   repulsive, r^2 < 1e-10 skipped
+    TreeLeaf = 1,  // octree.cpp:105-125, bvh.cpp:150-176   attractive, r^2 < 1e-9 skipped
+    FmmP2P = 2     // fmm_parlay.cpp:992-1020   attractive, identical positions skipped, r^2 < 1e-10 smoothed by (1e-5)^2
+};
+
+// Forces from the listed leaf pairs only (zero for bodies in no leaf).  Throws std::runtime_error on invalid lists or
+// any device failure, like the solver wrappers of methods_hip.h; there is no CPU fallback.
+template <int D>
+std::vector<Vector<D>> leaf_pair_direct_forces_hip(const std::vector<Body<D>>& bodies, const LeafLists& lists, LeafLaw law);
+
+// Fixed-depth subdivision of the bodies' bounding box (2^depth cells per axis, box padded like fmm.cpp:386-387):
+// non-empty cells are the leaves, each leaf's list is itself followed by its non-empty adjacent cells -- the simplest
+// tree that produces the reference's neighbour-list structure (fmm.cpp:455-476).
+template <int D>
+LeafLists build_uniform_leaves(const std::vector<Body<D>>& bodies, int depth);
+
+// kernel time of the most recent leaf_pair_direct_forces_hip call on this thread (ms)
+float last_leaf_pair_kernel_ms();
+
+#endif

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "methods_cpu.h"
+#include "leaf_pairs_hip.h"
 #include "methods_hip.h"
 #include "utils_hip.h"
 
@@ -38,6 +39,7 @@ struct Options {
     std::string dump;               // prefix: write bodies and each method's forces as raw doubles
     double G = ::G;                 // --G: coupling constant of the HIP stepping loop (default: the reference's)
     int energy_every = 0;           // --energy-every k: log E and |dE/E0| every k steps of the loop
+    double softening = 0.0;         // --softening eps: Plummer-softened law in the stepping loop (extension; 0 = reference law)
     std::vector<int> devices;       // --gpus / --devices: shard the HIP rows over these GPUs (one process)
 };
 
@@ -161,12 +163,53 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
         out << std::endl;
     }
 
+    // Near-field (leaf-pair direct sums) of the tree codes on the device: `-m p`.  The tree methods themselves are out of
+    // scope; this row times the step they would hand to the GPU (FMM_Parlay<D>::p2p_phase, fmm_parlay.cpp:916-1022) on a
+    // fixed-depth subdivision with ~64 bodies per leaf and 3^D neighbour lists.
+    if (m.find('p') != std::string::npos) {
+        int depth = 1;
+        while (depth < 10 && static_cast<double>(n) / std::pow(2.0, depth * D) > 64.0) ++depth;
+        out << "Near-field direct sums on HIP (FMM P2P law, uniform leaves of depth " << depth << "):" << std::endl;
+        Forces forces;
+        const LeafLists lists = build_uniform_leaves<D>(bodies, depth);   // host-side tree stand-in, not timed
+        if (!opt.dump.empty()) {
+            dump_raw(opt.dump + "_leaf_offsets.u32", lists.leaf_offsets);
+            dump_raw(opt.dump + "_leaf_bodies.u32", lists.leaf_bodies);
+            dump_raw(opt.dump + "_list_offsets.u32", lists.list_offsets);
+            dump_raw(opt.dump + "_list_sources.u32", lists.list_sources);
+        }
+        const long long us = safely_execute(log, "NearField_HIP", [&] {
+            forces = leaf_pair_direct_forces_hip<D>(bodies, lists, LeafLaw::FmmP2P);
+            return 0;
+        });
+        if (us >= 0) {
+            const double seconds = static_cast<double>(us) / 1e6;
+            csv << "NearField_HIP," << n << "," << D;
+            write_time(csv, seconds);
+            if (opt.accuracy) csv << ",";
+            csv << std::endl;
+            double pairs = 0.0;
+            for (std::size_t t = 0; t < lists.leaves(); ++t)
+                for (std::uint32_t e = lists.list_offsets[t]; e < lists.list_offsets[t + 1]; ++e)
+                    pairs += static_cast<double>(lists.leaf_offsets[t + 1] - lists.leaf_offsets[t]) *
+                             static_cast<double>(lists.leaf_offsets[lists.list_sources[e] + 1] - lists.leaf_offsets[lists.list_sources[e]]);
+            out << "Time taken: " << seconds << " s  (" << lists.leaves() << " leaves, " << pairs << " pair terms, kernel "
+                << last_leaf_pair_kernel_ms() << " ms)" << std::endl;
+            print_validation_forces<D>(forces, n, log);
+            print_validation_forces<D>(forces, n, std::cout);
+            if (!opt.dump.empty()) dump_raw(opt.dump + "_NearField_HIP.f64", forces);
+        }
+        out << std::endl;
+    }
+
     if (opt.steps > 0 && run_hip) {
-        out << "Leapfrog (kick-drift) on HIP: " << opt.steps << " steps, dt = " << opt.dt << ", G = " << opt.G << std::endl;
+        out << "Leapfrog (kick-drift) on HIP: " << opt.steps << " steps, dt = " << opt.dt << ", G = " << opt.G;
+        if (opt.softening > 0.0) out << ", softening = " << opt.softening;
+        out << std::endl;
         std::vector<Body<D>> state = bodies;
         double kernel_s = 0.0;
         const long long us = safely_execute(log, "Leapfrog_HIP", [&] {
-            HipSimulation<D> sim(bodies, opt.G);
+            HipSimulation<D> sim(bodies, opt.G, opt.softening);
             double ke = 0.0, pe = 0.0, e0 = 0.0;
             const int chunk = opt.energy_every > 0 ? opt.energy_every : opt.steps;
             if (opt.energy_every > 0) {
@@ -212,12 +255,14 @@ void usage(const char* argv0) {
               << "  -a, --accuracy <0|1> Enable accuracy calculation (default: 0 - OFF)" << std::endl
               << "  -m, --methods <str> Specify which methods to run (default: all)" << std::endl
               << "                      a=bruteforce (CPU rows + HIP), g=HIP brute force only," << std::endl
+              << "                      p=near-field (leaf-pair) direct sums of the tree codes on HIP," << std::endl
               << "                      b=barnes-hut, h=hilbert bvh, f=fmm (not built in this tier)" << std::endl
               << "      --seed <int>    Reproducible bodies (default: random_device, like the reference)" << std::endl
               << "      --init <uniform|plummer>  Initial condition (default: uniform)" << std::endl
               << "      --steps <k>     Also run k kick-drift steps on the device" << std::endl
               << "      --dt <t>        Time step for --steps (default: 1)" << std::endl
               << "      --G <value>     Coupling constant of the stepping loop (default: the reference's 4.471e-21)" << std::endl
+              << "      --softening <eps> Plummer softening of the stepping loop's pair law (extension; default 0 = the reference's law)" << std::endl
               << "      --energy-every <k> Log total energy and |dE/E0| every k steps (potential matching the reference law)" << std::endl
               << "      --gpus <g>      Shard the HIP rows over GPUs 0..g-1 of this node (one process, RCCL all-gather per step)" << std::endl
               << "      --devices <list> Same with an explicit device list, e.g. 0,0,0 = three virtual ranks on GPU 0" << std::endl
@@ -251,9 +296,9 @@ int main(int argc, char* argv[]) {
             opt.methods = argv[++i];
             opt.override_bf_limit = opt.methods == "a";
             for (char c : opt.methods)
-                if (std::string("abhfg").find(c) == std::string::npos) {
+                if (std::string("abhfgp").find(c) == std::string::npos) {
                     std::cerr << "Error: Invalid method '" << c << "'" << std::endl
-                              << "Valid methods: a=bruteforce, g=hip bruteforce, b=barnes-hut, h=bvh, f=fmm" << std::endl;
+                              << "Valid methods: a=bruteforce, g=hip bruteforce, p=hip near-field sums, b=barnes-hut, h=bvh, f=fmm" << std::endl;
                     return 1;
                 }
         } else if (arg == "--seed" && has_value) {
@@ -266,6 +311,8 @@ int main(int argc, char* argv[]) {
             opt.G = std::stod(argv[++i]);
         } else if (arg == "--energy-every" && has_value) {
             opt.energy_every = std::stoi(argv[++i]);
+        } else if (arg == "--softening" && has_value) {
+            opt.softening = std::stod(argv[++i]);
         } else if (arg == "--gpus" && has_value) {
             const int g = std::stoi(argv[++i]);
             if (g < 1 || g > 64) {
@@ -302,7 +349,7 @@ int main(int argc, char* argv[]) {
     }
 
     set_hip_devices(opt.devices);
-    if (opt.methods.empty() || opt.methods.find_first_of("ag") != std::string::npos)
+    if (opt.methods.empty() || opt.methods.find_first_of("agp") != std::string::npos)
         warm_up_hip();  // device start-up stays out of the timed rows; a missing GPU surfaces in the HIP row itself
     const std::string run_id = get_run_id();
     try {

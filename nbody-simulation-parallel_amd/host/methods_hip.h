@@ -36,7 +36,8 @@ void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps);
 template <int D>
 class HipSimulation {
 public:
-    HipSimulation(const std::vector<Body<D>>& bodies, double G);
+    // softening > 0: Plummer-softened pair law (an extension, nbx_ctx_set_softening); 0 = the reference's law
+    HipSimulation(const std::vector<Body<D>>& bodies, double G, double softening = 0.0);
     ~HipSimulation();
     HipSimulation(const HipSimulation&) = delete;
     HipSimulation& operator=(const HipSimulation&) = delete;

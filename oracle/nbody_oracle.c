@@ -465,3 +465,61 @@ int oracle_leaf_pair_magnitude_sums(const double* bodies, size_t n, int D, const
     }
     return 0;
 }
+
+/* ---- EXTENSION checker: Plummer-softened pair law (nbx_ctx_set_softening) -----------------------------------
+ * NOT in the reference (its brute force is unsoftened; utils.h:24 defines an unused SOFTENING constant):
+ * nothing to pin against.  The law is the reference's with r^2 -> r^2 + eps^2 and without the r^2 < 1e-10 skip:
+ *   F_i = -(G m_i) sum_{j != i} m_j (p_j - p_i) / (r^2 + eps^2)^2 ,  U = sum_{i<j} G m_i m_j / (2 (r^2 + eps^2)).
+ * For eps -> 0 and no pair below 1e-5 it tends to oracle_brute_force_omp_2 (tests/test_leaf_pairs_cpu.py checks that).
+ * rows == NULL: all bodies.  sums (optional) receives sum_j |f_ij|. */
+int oracle_force_rows_softened(const double* bodies, size_t n, int D, double eps, const int64_t* rows, size_t nrows,
+                               double* out, double* sums) {
+    if (D != 2 && D != 3) return -1;
+    const size_t cnt = rows ? nrows : n;
+    const double e2 = eps * eps;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t r = 0; r < cnt; ++r) {
+        const size_t i = rows ? (size_t)rows[r] : r;
+        const double* pi = POS(bodies, i, D);
+        const double gmi = ORACLE_G * MASS(bodies, i, D);
+        double acc[3] = {0.0, 0.0, 0.0}, s = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            if (i == j) continue;
+            const double* pj = POS(bodies, j, D);
+            double d[3] = {0.0, 0.0, 0.0}, r2 = 0.0;
+            for (int k = 0; k < D; ++k) { d[k] = pj[k] - pi[k]; r2 += d[k] * d[k]; }
+            const double q = r2 + e2;
+            const double wgt = gmi * MASS(bodies, j, D) / (q * q);
+            for (int k = 0; k < D; ++k) acc[k] -= wgt * d[k];
+            s += wgt * sqrt(r2);
+        }
+        for (int k = 0; k < D; ++k) out[r * D + k] = acc[k];
+        if (sums) sums[r] = s;
+    }
+    return 0;
+}
+
+int oracle_energy_softened(const double* bodies, size_t n, int D, double eps, double* out) {
+    double ke = 0.0, pe = 0.0;
+    const double e2 = eps * eps;
+#pragma omp parallel for reduction(+ : ke, pe) schedule(dynamic, 64)
+    for (size_t i = 0; i < n; ++i) {
+        const double* xi = POS(bodies, i, D);
+        const double* vi = VEL(bodies, i, D);
+        const double mi = MASS(bodies, i, D);
+        double v2 = 0.0;
+        for (int k = 0; k < D; ++k) v2 += vi[k] * vi[k];
+        ke += 0.5 * mi * v2;
+        double row = 0.0;
+        for (size_t j = i + 1; j < n; ++j) {
+            const double* xj = POS(bodies, j, D);
+            double r2 = 0.0;
+            for (int k = 0; k < D; ++k) { double d = xj[k] - xi[k]; r2 += d * d; }
+            row += MASS(bodies, j, D) / (r2 + e2);
+        }
+        pe += 0.5 * ORACLE_G * mi * row;
+    }
+    out[0] = ke;
+    out[1] = pe;
+    return 0;
+}

@@ -114,6 +114,25 @@ class Oracle:
     def num_threads(self):
         return self.lib.oracle_num_threads()
 
+    # ---- extension checker: softened law (nbx_ctx_set_softening); nothing in the reference to pin it to ----
+    def force_rows_softened(self, bodies, eps, rows=None):
+        """(forces, magnitude sums) of the softened law for the given rows (all bodies when rows is None)."""
+        d = self._dim(bodies)
+        if rows is None:
+            cnt, rp = bodies.shape[0], None
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            cnt, rp = rows.size, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        out, sums = np.zeros((cnt, d)), np.zeros(cnt)
+        rc = self.lib.oracle_force_rows_softened(_p(bodies), _sz(bodies.shape[0]), d, ctypes.c_double(eps), rp, _sz(cnt), _p(out), _p(sums))
+        assert rc == 0
+        return out, sums
+
+    def energy_softened(self, bodies, eps):
+        out = np.zeros(2)
+        self.lib.oracle_energy_softened(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(eps), _p(out))
+        return out[0], out[1]
+
     # ---- SURVEY 8(f-4): leaf-pair direct sums (law 0 brute force, 1 tree leaf, 2 FMM P2P) ----
     def _leaf_call(self, fn, bodies, leaves, law, width):
         d = self._dim(bodies)

@@ -100,3 +100,19 @@ def test_sweep_over_gpu_counts(tmp_path):
     for n in (20000, 60000):
         assert counts[(n, 1)]["Distinct Devices"] == "1" and counts[(n, 2)]["Distinct Devices"] == "1"
         assert float(counts[(n, 2)]["Pair Interactions/s (kernel)"]) > 0 and counts[(n, 2)]["Kernel Speed-up vs 1 GPU"] != ""
+
+
+def test_near_field_row_through_the_cpp_wrapper(tmp_path, oracle):
+    """`-m p`: leaf_pair_direct_forces_hip<3> (host/leaf_pairs_hip.cpp -> nbx_leaf_pair_forces) on the leaves built by the
+    C++ side, against the oracle's restatement of fmm_parlay.cpp:992-1020 on the same leaf lists."""
+    n = 50000
+    p = _run(tmp_path, "-N", str(n), "-m", "p", "--seed", "9", "--dump", "d")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
+    leaves = tuple(np.fromfile(os.path.join(tmp_path, f"d_{k}.u32"), dtype=np.uint32)
+                   for k in ("leaf_offsets", "leaf_bodies", "list_offsets", "list_sources"))
+    f = np.fromfile(os.path.join(tmp_path, "d_NearField_HIP.f64")).reshape(n, 3)
+    br = oracle.round_inputs_to_f32(bodies)
+    assert_force_parity(f, oracle.leaf_pair_forces(br, leaves, 2), oracle.leaf_pair_magnitude_sums(br, leaves, 2), "near-field harness row")
+    csv = glob.glob(os.path.join(tmp_path, "results", f"run_*_N_{n}_3D.csv"))[0]
+    assert any(l.startswith(f"NearField_HIP,{n},3,") for l in open(csv).read().splitlines())

@@ -1,0 +1,100 @@
+"""GPU: the softened pair law (nbx_ctx_set_softening) -- an EXTENSION: the reference's brute force is unsoftened
+(SURVEY F4), so the checker is the oracle's own restatement of  a_i = sum_j m_j d/(r^2+eps^2)^2  in fp64 ("parity
+unpinned": nothing in the reference to pin it to).  What it buys is in the last test: under the unsoftened law a
+fixed-step kick/drift must resolve the closest pair (tests/test_gpu_config5.py); softened at the inter-particle scale
+the Plummer sphere of BASELINE config 5 evolves for dynamical times with a small energy error."""
+import numpy as np
+import pytest
+
+from oracle_lib import assert_force_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+@pytest.mark.parametrize("eps", (1.0e-3, 50.0, 2.0e5))
+def test_softened_forces_match_the_checker(nbx, oracle, dim, eps):
+    n = 6000
+    b = oracle.generate(90 + dim, n, dim)
+    b[11, :dim] = b[10, :dim]                                   # coincident pair: zero force between them, finite weights
+    b[21, :dim] = b[20, :dim]; b[21, 0] += 3.0                   # a close pair, softened or not depending on eps
+    b = oracle.round_inputs_to_f32(b)
+    ref, S = oracle.force_rows_softened(b, eps)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_softening(eps)
+        assert c.effective_tuning()[0].startswith("fast")
+        c.compute_accel()
+        f = c.forces(oracle.G)
+        assert_force_parity(f, ref, S, f"softened eps={eps} D={dim}")
+        c.compute_accel()
+        assert np.array_equal(f, c.forces(oracle.G))
+        c.set_softening(0.0)                                    # back to the reference law
+        c.compute_accel()
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "eps=0 again")
+    for r in range(3):                                          # sharded passes
+        with nbx.Context(n, dim, n_shards=3, shard=r) as c:
+            c.upload(b)
+            c.set_softening(eps)
+            c.compute_accel(nbx.SRC_LOCAL)
+            c.compute_accel(nbx.SRC_REMOTE)
+            lo = r * c.shard_len
+            assert_force_parity(c.forces(oracle.G), ref[lo:lo + c.count], S[lo:lo + c.count], f"softened shard {r}")
+
+
+def test_softened_energy_and_argument_checks(nbx, oracle):
+    n, dim = 3000, 3
+    b = oracle.round_inputs_to_f32(oracle.generate(12, n, dim))
+    b[11, :3] = b[10, :3]
+    for eps in (1.0e-2, 1.0e4):
+        ke_ref, pe_ref = oracle.energy_softened(b, eps)
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.set_softening(eps)
+            ke, pe = c.energy(oracle.G)
+        assert abs(ke - ke_ref) <= 1e-13 * ke_ref and abs(pe - pe_ref) <= 2e-6 * pe_ref, (eps, pe, pe_ref)
+        tot = np.zeros(2)
+        for r in range(2):
+            with nbx.Context(n, dim, n_shards=2, shard=r) as c:
+                c.upload(b)
+                c.set_softening(eps)
+                tot += c.energy(oracle.G)
+        assert abs(tot[1] - pe_ref) <= 2e-6 * pe_ref
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        for bad in (-1.0, 1e-9, float("nan"), 1e20):
+            with pytest.raises(nbx.NbxError):
+                c.set_softening(bad)
+        c.set_softening(1e-6)                                   # m / eps^4 = 1e8 / 1e-24 = 1e32: representable
+        c.compute_accel()
+    heavy = b.copy()
+    heavy[5, -1] = float(np.float32(3.0e15))                    # 3e15 / 1e-24 overflows fp32
+    with nbx.Context(n, dim) as c:
+        c.upload(heavy)
+        c.set_softening(1e-6)
+        with pytest.raises(nbx.NbxError):
+            c.compute_accel()
+        c.set_softening(1.0)
+        c.compute_accel()
+
+
+def test_softened_plummer_sphere_conserves_energy_over_dynamical_times(nbx):
+    """BASELINE config 5's system at N = 262,144 with the law softened at the inter-particle scale: eps = 1500 (median
+    nearest-neighbour distance of this sample ~3,100), G = 1e4 so that t_dyn = sqrt(a^4/(G M)) = 100, dt = 0.5,
+    400 steps = 2 t_dyn.  Unsoftened, the same G and dt give |dE/E0| ~ 1e2 from the first kick of the closest pairs."""
+    n = 1 << 18
+    b = nbx.plummer_bodies(n, 3, seed=5, a=1.0e5, total_mass=1.0e12)
+    G, dt, eps = 1.0e4, 0.5, 1500.0
+    with nbx.Context(n, 3) as c:
+        c.upload(b)
+        c.set_softening(eps)
+        e0 = sum(c.energy(G))
+        worst = 0.0
+        for _ in range(8):
+            c.step(dt, 50, G)
+            ke, pe = c.energy(G)
+            worst = max(worst, abs(ke + pe - e0) / e0)
+        ms, launches = c.kernel_time()
+    print(f"\nsoftened Plummer N={n}: max |dE/E0| = {worst:.3e} over 400 steps (2 t_dyn), KE/E0 at the end {ke / e0:.3f}, {ms:.1f} ms per step")
+    assert ke > 0.2 * e0, "two dynamical times must convert a sizeable part of the potential energy"
+    assert worst < 2e-2

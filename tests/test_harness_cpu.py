@@ -86,3 +86,22 @@ def test_aggregate_results_has_the_analysis_columns(exe, tmp_path):
     lines = open(os.path.join(tmp_path, "results", "aggregated_results.csv")).read().strip().splitlines()
     assert lines[0] == "Bodies,Method,Dimension,Average Runtime (s)"
     assert any(l.startswith("200,BruteForce_Sequential,3,") for l in lines[1:])
+
+
+@pytest.mark.parametrize("dim", (2, 3))
+def test_cpp_leaf_builder_equals_python_leaf_builder(exe, tmp_path, dim):
+    """`-m p`: host/leaf_pairs_hip.cpp build_uniform_leaves<D> and leaves.py uniform_grid_leaves must produce the same
+    CSR arrays (the GPU row itself fails loudly here: no device, no fallback)."""
+    import nbody_amd as nbx
+    n = 3000
+    p = _run(exe, tmp_path, "-N", str(n), "-d", str(dim), "-m", "p", "--seed", "3", "--dump", "d")
+    assert p.returncode == 0
+    assert "Error executing NearField_HIP" in p.stderr and "no CPU fallback" in p.stderr
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 2 * dim + 1)
+    depth = 1
+    while depth < 10 and n / 2.0 ** (depth * dim) > 64.0:
+        depth += 1
+    want = nbx.leaves.uniform_grid_leaves(bodies, dim, depth)
+    for name, w in zip(("leaf_offsets", "leaf_bodies", "list_offsets", "list_sources"), want):
+        got = np.fromfile(os.path.join(tmp_path, f"d_{name}.u32"), dtype=np.uint32)
+        assert np.array_equal(got, w), name

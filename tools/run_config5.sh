@@ -3,16 +3,20 @@
 # sharded over the GPUs of one node (one process, RCCL all-gather of positions per step on a second stream).
 # Parameters as stated in tests/test_gpu_config5.py: a = 1e5, M = 1e12, seed 5, G = 0.05, dt = 0.5
 # (the unsoftened law makes the closest pair, not the sphere, set the admissible G dt^2 -- see that file).
-#   tools/run_config5.sh            # 8 GPUs, 1000 steps (~8 min at 8 x 3.2e13 pair-interactions/s aggregate)
+#   tools/run_config5.sh            # 8 GPUs, 1000 steps of the reference's unsoftened law (~8 min at 8 GPUs)
 #   GPUS=1 STEPS=20 tools/run_config5.sh
+#   SOFTENING=600 G=1e4 tools/run_config5.sh   # physically resolved variant: softened at the inter-particle scale
+#                                              # (median nearest neighbour 1230), t_dyn = 100, 1000 steps = 5 t_dyn
 set -euo pipefail
 cd "$(dirname "$0")/.."
 GPUS="${GPUS:-8}"
 STEPS="${STEPS:-1000}"
 EVERY="${EVERY:-50}"
+G="${G:-0.05}"
+SOFTENING="${SOFTENING:-0}"
 OUT="${OUT:-gpurun_out/config5_${GPUS}gpu_${STEPS}steps.log}"
 mkdir -p "$(dirname "$OUT")"
 [ -x ./nbody_sim ] || make nbody_sim
-./nbody_sim -N 4194304 -d 3 -m g --init plummer --seed 5 --G 0.05 --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" --gpus "$GPUS" | tee "$OUT"
+./nbody_sim -N 4194304 -d 3 -m g --init plummer --seed 5 --G "$G" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" --gpus "$GPUS" | tee "$OUT"
 grep -E "^step |Time taken|Kernel time" "$OUT" > "${OUT%.log}.summary.txt"
 echo "summary: ${OUT%.log}.summary.txt"
