@@ -47,7 +47,17 @@ def host_facts():
         phys = int(facts["Core(s) per socket"]) * int(facts["Socket(s)"])
     except (KeyError, ValueError):
         phys = facts["usable_hw_threads"]
-    facts["physical_cores_usable"] = max(1, min(phys, facts["usable_hw_threads"]))
+    quota = None   # cgroup CPU bandwidth limit: "max" or "<quota> <period>" -- more threads than that are only time-sliced
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    facts["cgroup_cpu_quota"] = quota
+    usable = min(phys, facts["usable_hw_threads"])
+    if quota:
+        usable = min(usable, int(quota + 0.5))
+    facts["physical_cores_usable"] = max(1, usable)
     return facts
 
 
@@ -69,8 +79,9 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
     """Reported baseline (not the target): the reference's own brute_force_omp_n_body_2 object code
     (oracle/_ref, kind "reference") or the oracle port of it (kind "port") on a bounded sample of
     the same workload, timed on this host's cores: at 16 threads (the box's CPU share for one GPU, the primary
-    figure) and, when the process may use more, on all physical cores (also omp_1, the reference's faster
-    symmetric variant).  value = ordered pair interactions/s (N(N-1) per evaluation for every solver, so the
+    figure) and, when the process may use more (sockets x cores, capped by the affinity mask AND the cgroup CPU quota --
+    the GPU boxes of this pool grant exactly 16 CPUs, so there the two coincide), on all usable physical cores (also
+    omp_1, the reference's faster symmetric variant).  value = ordered pair interactions/s (N(N-1) per evaluation for every solver, so the
     figures compare with the GPU's; the symmetric omp_1 evaluates half as many pairs)."""
     import subprocess
     import numpy as np

@@ -9,7 +9,7 @@
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
 // forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
 // leaf order as SoA fp32 (coalesced streams), and the work is target-leaf-major: one 128-lane workgroup (two
-// wave64) owns up to 128 targets of ONE leaf -- one target per lane, fp32 tile sums flushed into fp64 second-level
+// wave64; one wave64 when the mean leaf holds <= 80 bodies) owns up to 128 (64) targets of ONE leaf -- one target per lane, fp32 tile sums flushed into fp64 second-level
 // accumulators -- and walks that leaf's source-leaf list, staging each source leaf through LDS in tiles of 128 bodies
 // {x,y,z,m}; all lanes read the same LDS address (ds_read_b128 broadcast).  No atomics, a fixed summation order
 // (list order, then leaf order), every output written once.  Leaves are small (the reference caps them at 100 bodies,
@@ -25,7 +25,10 @@ using namespace nbx;
 
 namespace {
 
-constexpr int kLeafBlock = 128;   // targets per workgroup = source bodies per LDS tile
+// targets per workgroup = source bodies per LDS tile: 128 lanes (two wave64), or one wave64 when the leaves are small
+// (the mean leaf of the reference's trees is well under 100 bodies, methods.h:26) so that fewer lanes idle
+constexpr int kLeafBlock = 128;
+constexpr int kLeafBlockSmall = 64;
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
 constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
@@ -38,7 +41,7 @@ static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double
 struct TargetBlock {
     uint32_t leaf;     // target leaf
     uint32_t first;    // first target slot (leaf order)
-    uint32_t count;    // <= kLeafBlock
+    uint32_t count;    // <= the launch's block size
 };
 
 struct LeafArgs {
@@ -84,9 +87,9 @@ __device__ __forceinline__ void leaf_interact(float4 s, float ix, float iy, floa
     if (D == 3) az = __builtin_fmaf(w, dz, az);
 }
 
-template <int D, int LAW>
-__global__ __launch_bounds__(kLeafBlock) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[kLeafBlock];
+template <int D, int LAW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[BLOCK];
     const unsigned tid = threadIdx.x;
     const TargetBlock tb = a.blocks[blockIdx.x];
     const bool valid = tid < tb.count;
@@ -97,8 +100,8 @@ __global__ __launch_bounds__(kLeafBlock) void leaf_pair_kernel(LeafArgs a) {
     for (uint32_t e = e0; e < e1; ++e) {                       // wave-uniform walk of the leaf's source list
         const uint32_t s = a.list_sources[e];
         const uint32_t b0 = a.leaf_offsets[s], b1 = a.leaf_offsets[s + 1];
-        for (uint32_t base = b0; base < b1; base += kLeafBlock) {
-            const uint32_t cnt = (b1 - base < (uint32_t)kLeafBlock) ? b1 - base : (uint32_t)kLeafBlock;
+        for (uint32_t base = b0; base < b1; base += BLOCK) {
+            const uint32_t cnt = (b1 - base < (uint32_t)BLOCK) ? b1 - base : (uint32_t)BLOCK;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tid < cnt) {
                 const uint32_t j = base + tid;
@@ -147,10 +150,11 @@ __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restr
 }
 
 typedef void (*LeafKernel)(LeafArgs);
+template <int BLOCK>
 LeafKernel pick(int dim, int law) {
     static const LeafKernel table[2][3] = {
-        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
-        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
+        {leaf_pair_kernel<2, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, BLOCK>},
+        {leaf_pair_kernel<3, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, BLOCK>}};
     return table[dim - 2][law];
 }
 
@@ -206,10 +210,14 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
     if (slots == 0) return NBX_OK;
 
+    size_t nonempty = 0;
+    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
+    // block size by the mean leaf: up to 80 bodies per leaf one wave64 per block wastes fewer lanes than two
+    const uint32_t block = (nonempty && slots / nonempty <= 80) ? (uint32_t)kLeafBlockSmall : (uint32_t)kLeafBlock;
     std::vector<TargetBlock> blocks;
     for (size_t l = 0; l < n_leaves; ++l)
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += kLeafBlock)
-            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < (uint32_t)kLeafBlock) ? leaf_offsets[l + 1] - f : (uint32_t)kLeafBlock});
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block)
+            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block});
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
@@ -250,7 +258,8 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     a.x = x; a.m = m; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
     a.blocks = d_blocks; a.acc = acc;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kLeafBlock), 0, d.stream, a);
+    hipLaunchKernelGGL(block == (uint32_t)kLeafBlockSmall ? pick<kLeafBlockSmall>(dim, law) : pick<kLeafBlock>(dim, law),
+                       dim3((unsigned)blocks.size()), dim3(block), 0, d.stream, a);
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)

@@ -396,7 +396,19 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
     else { L.chunk_first = 0; L.vchunks = c->n_shards - 1; L.chunk_skip = c->shard; L.accumulate = 1; }
     if (L.vchunks == 0) return NBX_OK;  // REMOTE with a single shard: nothing to add
-    const bool timed = !c->capturing && c->ev_used < kEventPairs;
+    if (!c->capturing && c->ev_used == kEventPairs) {
+        // event log full (512 launches since the last nbx_ctx_kernel_time): fold it into the running totals instead of
+        // silently dropping later launches.  One stream synchronisation per 512 launches.
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < c->ev_used; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+            c->bulk_ms_done += ms;
+        }
+        c->bulk_steps_done += c->ev_used;
+        c->ev_used = 0;
+    }
+    const bool timed = !c->capturing;
     if (timed && !c->ev0[c->ev_used]) {
         HIP_TRY(hipEventCreate(&c->ev0[c->ev_used]));
         HIP_TRY(hipEventCreate(&c->ev1[c->ev_used]));

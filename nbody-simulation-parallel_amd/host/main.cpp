@@ -146,6 +146,15 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
             csv << std::endl;
             out << "Time taken: " << seconds << " s" << std::endl;
             if (opt.accuracy) out << "Accuracy: " << std::to_string(accuracy) << "%" << std::endl;
+            if (method.label == hip_label && opt.accuracy) {
+                // the same metric without the force array leaving the device (nbx_ctx_accuracy); must agree with the host's
+                try {
+                    const double dev = brute_force_hip_accuracy<D>(bodies, reference);
+                    out << "Accuracy (device-side metric): " << std::to_string(dev) << "%" << (dev == accuracy ? "" : "  [differs from the host metric]") << std::endl;
+                } catch (const std::exception& e) {
+                    out << "Accuracy (device-side metric): unavailable (" << e.what() << ")" << std::endl;
+                }
+            }
             if (method.label == hip_label) {
                 const double kernel_s = last_hip_run_info().kernel_ms * 1e-3;
                 const double pairs = static_cast<double>(n) * static_cast<double>(n);

@@ -72,6 +72,19 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 }
 
 template <int D>
+double brute_force_hip_accuracy(const std::vector<Body<D>>& bodies, const std::vector<Vector<D>>& reference) {
+    if (reference.size() != bodies.size()) throw std::runtime_error("brute_force_hip_accuracy: reference size differs from the bodies");
+    struct Ctx { nbx_ctx* h = nullptr; ~Ctx() { nbx_ctx_destroy(h); } } c;
+    double percent = 0.0;
+    int rc = nbx_ctx_create(&c.h, device_ordinal(), D, bodies.size(), 1, 0);
+    if (!rc) rc = nbx_ctx_upload_bodies(c.h, bodies.data(), sizeof(Body<D>));
+    if (!rc) rc = nbx_ctx_compute_accel(c.h, NBX_SRC_ALL);
+    if (!rc) rc = nbx_ctx_accuracy(c.h, NBX_REFERENCE_G, reinterpret_cast<const double*>(reference.data()), &percent);
+    if (rc != NBX_OK) raise("brute_force_hip_accuracy", rc);
+    return percent;
+}
+
+template <int D>
 void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps) {
     g_info = HipRunInfo{};
     if (g_devices.size() > 1) {
@@ -140,5 +153,7 @@ template class HipSimulation<3>;
 // explicit instantiations, like nbody-sim-new/methods.cpp:452-499 does for the CPU solvers
 template std::vector<Vector<2>> brute_force_hip_n_body<2>(const std::vector<Body<2>>&);
 template std::vector<Vector<3>> brute_force_hip_n_body<3>(const std::vector<Body<3>>&);
+template double brute_force_hip_accuracy<2>(const std::vector<Body<2>>&, const std::vector<Vector<2>>&);
+template double brute_force_hip_accuracy<3>(const std::vector<Body<3>>&, const std::vector<Vector<3>>&);
 template void leapfrog_hip_n_body<2>(std::vector<Body<2>>&, double, int);
 template void leapfrog_hip_n_body<3>(std::vector<Body<3>>&, double, int);

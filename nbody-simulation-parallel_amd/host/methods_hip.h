@@ -51,6 +51,12 @@ private:
     int ranks_ = 1;
 };
 
+// The reference's accuracy metric (compute_accuracy, utils.h:170-219) evaluated ON THE DEVICE against `reference`
+// (nbx_ctx_accuracy): the device forces are never copied back -- what `-a 1` needs at sizes where the force array is
+// large.  Runs its own force evaluation on one GPU; returns the percentage.  Throws like the solvers.
+template <int D>
+double brute_force_hip_accuracy(const std::vector<Body<D>>& bodies, const std::vector<Vector<D>>& reference);
+
 // Timing of the most recent call on this thread, for pair-interactions/s and roofline reporting.
 struct HipRunInfo {
     float kernel_ms = 0.0f;   // force-kernel time only (hipEvent), summed over the call's launches

@@ -52,6 +52,16 @@ def test_hip_only_large_n_and_leapfrog(tmp_path, oracle):
     assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "harness sampled rows")
 
 
+def test_device_side_accuracy_in_the_harness(tmp_path):
+    """`-a 1`: the HIP row's accuracy is also evaluated on the device (brute_force_hip_accuracy -> nbx_ctx_accuracy)
+    and agrees with the host's compute_accuracy."""
+    import re
+    p = _run(tmp_path, "-N", "5000", "-a", "1", "--seed", "8")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    m = re.search(r"Accuracy \(device-side metric\): ([0-9.]+)%(.*)", p.stdout)
+    assert m and float(m.group(1)) == 100.0 and "differs" not in m.group(2), p.stdout[-1500:]
+
+
 def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
     """`--devices 0,0,0`: the C++ wrappers shard over three virtual ranks of GPU 0 (nbx_node_*)."""
     n = 20000

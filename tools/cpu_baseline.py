@@ -2,8 +2,9 @@
 (oracle/_ref/libnbody_ref.so = nbody-sim-new/methods.cpp built with the reference Makefile's flags) timed on the
 GPU box's host cores, same seeded uniform bodies as the GPU runs.
 
-Two thread counts: the box's CPU share for one GPU (16) and every hardware thread this process may run on
-(all physical cores when the box hands them out).  OpenMP and ParlayLib fix their pools at start-up, so each
+Two thread counts: the box's CPU share for one GPU (16) and all physical cores (sockets x cores, capped by the
+affinity mask).  NOTE the header line's `cgroup cpu.max`: the GPU boxes of this pool grant 16 CPUs of bandwidth
+(1600000/100000), so a 128-thread run there is time-sliced onto 16 CPUs' worth and is NOT an all-cores figure.  OpenMP and ParlayLib fix their pools at start-up, so each
 configuration runs in its own child process (this script re-invoked with --child).  One JSON line per
 (threads, solver, N) is appended to the output file; the header line carries lscpu / affinity / cgroup facts.
 
@@ -58,6 +59,8 @@ def child(threads, sizes, dim, seed):
         for v in (0, 1, 2, 3, 4):
             if v == 0 and (n > 65536 or threads != 16):
                 continue  # sequential path: once, at N = 65,536
+            if v >= 3 and n > 65536:
+                continue  # the ParlayLib twins run 5-10x slower than the OpenMP ones here: N = 65,536 only
             dt = ref.time_brute_force(v, b)
             pairs = n * (n - 1) / (2 if v in (0, 1, 3) else 1)   # symmetric variants evaluate each pair once
             print(json.dumps({"solver": SOLVERS[v] + f"<{dim}>", "n": n, "threads": 1 if v == 0 else threads,
@@ -95,11 +98,16 @@ def main():
         for c in counts:
             env = dict(os.environ, OMP_NUM_THREADS=str(c), PARLAY_NUM_THREADS=str(c), OMP_PROC_BIND="spread", OMP_PLACES="cores")
             t0 = time.perf_counter()
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(c), "--sizes", args.sizes,
-                                "--dim", str(args.dim), "--seed", str(args.seed)], env=env, capture_output=True, text=True)
-            f.write(p.stdout)
-            if p.returncode:
-                f.write(json.dumps({"threads": c, "error": p.stderr[-400:]}) + "\n")
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(c), "--sizes", args.sizes,
+                                  "--dim", str(args.dim), "--seed", str(args.seed)], env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, text=True)
+            for line in p.stdout:            # one line per finished solver: keep the file (and the terminal) moving
+                f.write(line)
+                f.flush()
+                print(f"[cpu_baseline] {c} threads: {line[:110].rstrip()} ...", flush=True)
+            err = p.stderr.read()
+            if p.wait():
+                f.write(json.dumps({"threads": c, "error": err[-400:]}) + "\n")
             f.flush()
             print(f"[cpu_baseline] {c} threads done in {time.perf_counter() - t0:.1f} s", flush=True)
     print(open(args.out).read())
