@@ -3,7 +3,7 @@ inputs) on BASELINE's uniform configs -- FULL N at N = 65,536 (oracle brute_forc
 target rows at N = 2^20 -- with the distribution of per-body relative errors, the condition numbers of the
 offenders and the max-abs acceleration error.  Test infrastructure (uses oracle/); prints JSON lines."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 import numpy as np

@@ -1,7 +1,8 @@
 """N = 2^22 (BASELINE config 5's size) on one GPU: sampled-row parity + timing; and one shard of 8."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import nbody_amd as nbx
 from oracle_lib import Oracle, assert_force_parity

@@ -8,7 +8,7 @@ affinity mask).  NOTE the header line's `cgroup cpu.max`: the GPU boxes of this 
 configuration runs in its own child process (this script re-invoked with --child).  One JSON line per
 (threads, solver, N) is appended to the output file; the header line carries lscpu / affinity / cgroup facts.
 
-usage: python tools/cpu_baseline.py [--out profiles/r2/cpu_baseline.jsonl] [--sizes 65536,262144] [--threads 16,all]"""
+usage: python tests/measure/cpu_baseline.py [--out profiles/r2/cpu_baseline.jsonl] [--sizes 65536,262144] [--threads 16,all]"""
 import argparse
 import json
 import os
@@ -16,7 +16,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SOLVERS = {0: "brute_force_seq_n_body", 1: "brute_force_omp_n_body_1", 2: "brute_force_omp_n_body_2",
            3: "brute_force_parlay_n_body_1", 4: "brute_force_parlay_n_body_2"}
 

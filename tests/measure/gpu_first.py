@@ -1,8 +1,9 @@
 """First GPU pass: parity of every force-kernel variant against the CPU oracle at small N and an
 interleaved A/B timing of all variants (one process) at larger N."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import nbody_amd as nbx
 from oracle_lib import Oracle, accel_errors

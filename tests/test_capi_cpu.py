@@ -96,3 +96,9 @@ def test_product_does_not_touch_the_oracle():
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "nbody_oracle" not in txt, f
     out = os.popen(f"ldd '{os.path.join(pkg, 'libnbody_hip.so')}'").read()
     assert "oracle" not in out and "nbody_ref" not in out
+    # product-side tools and the harness sources stay clear of it too (checker-using scripts live under tests/measure/)
+    for d in ("tools", "include"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith((".py", ".sh", ".h", ".hip")):
+                txt = open(os.path.join(ROOT, d, f)).read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt, f"{d}/{f}"

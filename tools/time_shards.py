@@ -2,11 +2,9 @@
 REMOTE force passes + kick/drift exactly as one rank of a G-GPU run would (without the all-gather)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import nbody_amd as nbx
-from oracle_lib import Oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-b = Oracle().generate(1, n, 3)
+b = nbx.uniform_bodies(n, 3, 1)
 base = None
 for G in (1, 2, 4, 8):
     with nbx.Context(n, 3, n_shards=G, shard=G // 2) as c:
