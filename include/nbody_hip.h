@@ -192,6 +192,13 @@ int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
  * epsilon must be 0 or in [1e-6, 1e15], and max|m| / epsilon^4 must be finite in fp32 (checked at the next force
  * evaluation).  Applies to compute_accel / step / energy of this context. */
 int nbx_ctx_set_softening(nbx_ctx* ctx, double epsilon);
+/* EXTENSION (SURVEY 5/7 `--law {reference,newton}`; the reference has one law): NBX_FORCE_LAW_REFERENCE (default) is the
+ * reference's repulsive m_j d / r^4 form; NBX_FORCE_LAW_NEWTON is the attractive, Plummer-softened Newtonian law
+ *   F_i = +G m_i sum_{j != i} m_j (p_j - p_i) / (r^2 + epsilon^2)^(3/2),   U = -sum_{i<j} G m_i m_j / sqrt(r^2 + epsilon^2),
+ * which needs a softening length > 0 (NBX_ERR_STATE at the next evaluation otherwise).  Same kernel with v_rsq_f32 in
+ * place of v_rcp_f32 and one more multiply.  Forces, kick/drift, energy and the accuracy metric all follow the law. */
+enum { NBX_FORCE_LAW_REFERENCE = 0, NBX_FORCE_LAW_NEWTON = 1 };
+int nbx_ctx_set_law(nbx_ctx* ctx, int law);
 /* The variant and slice count the next force evaluation will use (after upload). */
 int nbx_ctx_effective_tuning(nbx_ctx* ctx, int* variant, int* source_splits);
 int nbx_num_variants(void);
@@ -227,6 +234,7 @@ int nbx_node_upload_bodies(nbx_node* node, const void* bodies, size_t body_strid
 int nbx_node_verify_exchange(nbx_node* node, size_t* mismatches);
 int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
 int nbx_node_set_softening(nbx_node* node, double epsilon);   /* nbx_ctx_set_softening on every rank */
+int nbx_node_set_law(nbx_node* node, int law);                /* nbx_ctx_set_law on every rank */
 /* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
 /* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */

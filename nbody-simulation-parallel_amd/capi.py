@@ -53,6 +53,7 @@ ABI = [
     ("nbx_ctx_synchronize", _i, [_vp]),
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_ctx_set_softening", _i, [_vp, _d]),
+    ("nbx_ctx_set_law", _i, [_vp, _i]),
     ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
     ("nbx_num_variants", _i, []),
     ("nbx_variant_name", _c.c_char_p, [_i]),
@@ -65,6 +66,7 @@ ABI = [
     ("nbx_node_verify_exchange", _i, [_vp, _c.POINTER(_sz)]),
     ("nbx_node_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_node_set_softening", _i, [_vp, _d]),
+    ("nbx_node_set_law", _i, [_vp, _i]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
     ("nbx_node_synchronize", _i, [_vp]),
@@ -166,6 +168,7 @@ def leapfrog_hip_n_body(bodies: np.ndarray, dt: float, nsteps: int, G: float = R
 
 
 LAW_BRUTE, LAW_TREE_LEAF, LAW_FMM_P2P = 0, 1, 2
+FORCE_LAW_REFERENCE, FORCE_LAW_NEWTON = 0, 1
 
 
 def leaf_pair_forces_hip(bodies: np.ndarray, leaf_offsets, leaf_bodies, list_offsets, list_sources, law: int = LAW_FMM_P2P,
@@ -236,6 +239,10 @@ class Context:
     def set_softening(self, epsilon: float):
         """Extension: Plummer-softened pair law (epsilon = 0 restores the reference's unsoftened law)."""
         self._ck(self.lib.nbx_ctx_set_softening(self.h, float(epsilon)), "nbx_ctx_set_softening")
+
+    def set_law(self, law: int):
+        """Extension: FORCE_LAW_REFERENCE (default) or FORCE_LAW_NEWTON (attractive, softened; needs set_softening > 0)."""
+        self._ck(self.lib.nbx_ctx_set_law(self.h, int(law)), "nbx_ctx_set_law")
 
     def effective_tuning(self) -> Tuple[str, int]:
         v, s = ctypes.c_int(0), ctypes.c_int(0)
@@ -350,6 +357,9 @@ class Node:
 
     def set_softening(self, epsilon: float):
         self._ck(self.lib.nbx_node_set_softening(self.h, float(epsilon)), "nbx_node_set_softening")
+
+    def set_law(self, law: int):
+        self._ck(self.lib.nbx_node_set_law(self.h, int(law)), "nbx_node_set_law")
 
     def forces(self, G: float = REFERENCE_G) -> np.ndarray:
         out = np.empty((self.n_total, self.dim), dtype=np.float64)

@@ -70,7 +70,9 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
 //                 (1/r2a, 1/r2b) = W * (r2b, r2a)  -- v_mul, v_rcp, v_pk_mul(op_sel swap) instead of v_rcp x2
 //                 (3.45 ns -> 3.0 ns of the 27.7 ns body, tools/ubench_valu.hip).  r2a*r2b must stay finite:
 //                 launched only when every |coordinate| <= kOneRcpMaxCoord (nbx_internal.h).
-template <int D, int PAIRS, int ONE_RCP>
+// NEWTON = 1 (softened Newtonian law, an extension): the weight is m (r^2+eps^2)^-3/2 -- v_rsq_f32 in place of v_rcp_f32
+// and one more v_pk_mul: 14 VALU per two pairs.
+template <int D, int PAIRS, int ONE_RCP, int NEWTON = 0>
 __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, float sm, const f2 (&ix)[PAIRS],
                                                  const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
                                                  f2 (&ay)[PAIRS], f2 (&az)[PAIRS], const f2 bias) {
@@ -97,12 +99,19 @@ __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f
         for (int q = 0; q < PAIRS; ++q) W[q] = __builtin_amdgcn_rcpf(W[q]);
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) w[q] = f2{W[q], W[q]} * __builtin_shufflevector(r2[q], r2[q], 1, 0);
+    } else if (NEWTON) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rsqf(r2[q].x); w[q].y = __builtin_amdgcn_rsqf(r2[q].y); }
     } else {
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
     }
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) r2[q] = f2{sm, sm} * w[q];
+    if (NEWTON) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) r2[q] = r2[q] * w[q];
+    }
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) w[q] = r2[q] * w[q];
 #pragma unroll
@@ -238,6 +247,8 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // SOFT = 1: Plummer-softened law  a_i = sum_j m_j d / (r^2 + eps^2)^2  (nbx_ctx_set_softening; an extension -- the
 // reference's brute force has no softening).  The bias of r^2 is then eps^2 itself, every pair is counted,
 // and there is no close set: close_blocks = 0, bad_flag is not read.
+// SOFT = 2: softened NEWTONIAN law  a_i = sum_j m_j d / (r^2 + eps^2)^(3/2)  (nbx_ctx_set_law; the `--law newton` of
+// SURVEY 5/7; attractive -- the sign is applied with G by the consumers).  Never combined with ONE_RCP.
 template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll UNROLL
         for (int j = 0; j < kTile; ++j) {
             const float4 s = cur[j];
-            interact2_staged<D, PAIRS, ONE_RCP>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az, bias);
+            interact2_staged<D, PAIRS, (SOFT == 2) ? 0 : ONE_RCP, SOFT == 2>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az, bias);
         }
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
@@ -464,7 +475,8 @@ __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Potential kernel (diagnostic for energy-drift checks, BASELINE config 5): phi_i = sum_j m_j / r_ij^2
+// Potential kernel (diagnostic for energy-drift checks, BASELINE config 5; SOFT = 1: sum_{j != i} m_j/(r^2+eps^2),
+// SOFT = 2: sum_{j != i} m_j/sqrt(r^2+eps^2) for the Newtonian law): phi_i = sum_j m_j / r_ij^2
 // over the selected sources with the reference's skip rule, so that the energy matching the reference
 // law is U = sum_i (G m_i / 4) phi_i  (F = -grad U for U = sum_{i<j} G m_i m_j / (2 r^2)).
 // Same tiling as the exact force kernel, two targets per lane, fp64 second level; 9 VALU per pair.
@@ -518,7 +530,8 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
                     const float dx = s.x - ix[q], dy = s.y - iy[q];
                     float r2 = __builtin_fmaf(dy, dy, dx * dx);
                     if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
-                    const float wgt = ((unsigned)q == rel && (unsigned)j == tid) ? 0.0f : __builtin_amdgcn_rcpf(r2 + a.eps2);
+                    const float wgt = ((unsigned)q == rel && (unsigned)j == tid) ? 0.0f
+                                      : (SOFT == 2 ? __builtin_amdgcn_rsqf(r2 + a.eps2) : __builtin_amdgcn_rcpf(r2 + a.eps2));
                     p[q] = __builtin_fmaf(s.w, wgt, p[q]);
                 }
             }
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
                     float r2 = __builtin_fmaf(dy, dy, dx * dx);
                     if (D == 3) { const float dz = s.z - iz[q]; r2 = __builtin_fmaf(dz, dz, r2); }
                     const float r2g = SOFT ? r2 + a.eps2 : ((r2 < kR2SkipF) ? __builtin_inff() : r2);
-                    p[q] = __builtin_fmaf(s.w, __builtin_amdgcn_rcpf(r2g), p[q]);
+                    p[q] = __builtin_fmaf(s.w, SOFT == 2 ? __builtin_amdgcn_rsqf(r2g) : __builtin_amdgcn_rcpf(r2g), p[q]);
                 }
             }
         }
@@ -546,10 +559,11 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 }
 
 // ---- variant table: the default fast kernel, its one-reciprocal comparator, and the exact (guarded) kernel ------
-#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0, nullptr, nullptr
+#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0, nullptr, nullptr, nullptr, nullptr
 #define NBX_FAST(PAIRS, WAVES, UNROLL, ONE_RCP) \
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP>, 1, 256, ONE_RCP, \
-    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 1>
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 0, 2>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 0, 2>
 
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
@@ -572,6 +586,7 @@ CloseKernels close_kernels() {
     k.scatter[0] = scatter_close_kernel<2>;   k.scatter[1] = scatter_close_kernel<3>;
     k.potential[0] = potential_kernel<2, 0>;  k.potential[1] = potential_kernel<3, 0>;
     k.potential_soft[0] = potential_kernel<2, 1>; k.potential_soft[1] = potential_kernel<3, 1>;
+    k.potential_newton[0] = potential_kernel<2, 2>; k.potential_newton[1] = potential_kernel<3, 2>;
     return k;
 }
 

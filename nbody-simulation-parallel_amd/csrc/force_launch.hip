@@ -84,6 +84,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.eps2 = L.eps2;
     const bool soft = L.eps2 > 0.0f;
     if (soft && !(V.fast && V.soft2 && V.soft3)) return hipErrorInvalidValue;   // softened law: fast kernels only
+    if (L.law != 0 && !(soft && V.newton2 && V.newton3)) return hipErrorInvalidValue;   // Newtonian law: softened only
     // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
@@ -124,7 +125,8 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     }
     dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(soft ? ((dim == 3) ? V.soft3 : V.soft2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
+    hipLaunchKernelGGL(L.law ? ((dim == 3) ? V.newton3 : V.newton2)
+                             : soft ? ((dim == 3) ? V.soft3 : V.soft2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;
@@ -150,7 +152,8 @@ hipError_t launch_potential(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.chunk_skip = L.chunk_skip;
     a.splits = L.splits;
     a.eps2 = L.eps2;
-    hipLaunchKernelGGL(L.eps2 > 0.0f ? table().ck.potential_soft[dim - 2] : table().ck.potential[dim - 2], dim3(L.pad / 512u, (unsigned)L.splits, 1), dim3(256, 1, 1), 0, stream, a);
+    if (L.law != 0 && !(L.eps2 > 0.0f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(L.law ? table().ck.potential_newton[dim - 2] : L.eps2 > 0.0f ? table().ck.potential_soft[dim - 2] : table().ck.potential[dim - 2], dim3(L.pad / 512u, (unsigned)L.splits, 1), dim3(256, 1, 1), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -356,6 +356,15 @@ int nbx_ctx_set_softening(nbx_ctx* c, double epsilon) {
     return NBX_OK;
 }
 
+int nbx_ctx_set_law(nbx_ctx* c, int law) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (law != NBX_FORCE_LAW_REFERENCE && law != NBX_FORCE_LAW_NEWTON) return fail(NBX_ERR_INVALID, "unknown force law");
+    c->law = law;
+    c->have_accel = false;
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    return NBX_OK;
+}
+
 int nbx_ctx_effective_tuning(nbx_ctx* c, int* variant, int* source_splits) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
     const int v = effective_variant(c);
@@ -389,6 +398,8 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.pass = which; L.cacheable = (c->n_shards == 1 || which == NBX_SRC_LOCAL) ? 1 : 0;
     L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
     L.eps2 = (float)(c->softening * c->softening);
+    L.law = c->law;
+    if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     if (c->softening > 0.0 && !(c->mass_max / ((double)L.eps2 * (double)L.eps2) < 1.0e38))
         return fail(NBX_ERR_INVALID, "softening too small for these masses: m / eps^4 must stay finite in fp32");
     L.chunk_skip = INT_MAX; L.accumulate = 0;
@@ -427,7 +438,8 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
     int rc = set_device(c);
     if (rc) return rc;
     KickDriftArgs k;
-    k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = G; k.dt = dt;
+    // attractive (Newtonian) law: F = +(G m) a.  The kernels compute F = -(G m) a, so G goes in negated (exact in fp64).
+    k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = c->law ? -G : G; k.dt = dt;
     k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64;
     k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
     HIP_TRY(launch_kick_drift(k, c->stream));
@@ -442,7 +454,7 @@ namespace {
 // about capture is unavailable; the caller then steps eagerly.
 bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
-        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening)
+        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law)
         return true;
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -457,7 +469,7 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     const hipError_t ei = hipGraphInstantiate(&c->step_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
-    c->graph_eps = c->softening;
+    c->graph_eps = c->softening; c->graph_law = c->law;
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }
@@ -507,7 +519,7 @@ int nbx_ctx_get_forces(nbx_ctx* c, double G, double* out) {
     const size_t bytes = c->count * c->dim * sizeof(double);
     rc = ensure_stage(c, bytes ? bytes : 8);
     if (rc) return rc;
-    HIP_TRY(launch_export_forces(c->acc, c->splits, c->dim, c->pad, c->count, G, c->m64, c->stage, c->stream));
+    HIP_TRY(launch_export_forces(c->acc, c->splits, c->dim, c->pad, c->count, c->law ? -G : G, c->m64, c->stage, c->stream));
     if (bytes) HIP_TRY(hipMemcpyAsync(out, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NBX_OK;
@@ -523,7 +535,7 @@ int nbx_ctx_accuracy(nbx_ctx* c, double G, const double* reference_forces, doubl
     if (rc) return rc;
     unsigned* counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->stage) + bytes);  // 8-byte aligned tail
     if (bytes) HIP_TRY(hipMemcpyAsync(c->stage, reference_forces, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_accuracy(c->acc, c->splits, c->dim, c->pad, c->count, G, c->m64, c->stage, counter, c->stream));
+    HIP_TRY(launch_accuracy(c->acc, c->splits, c->dim, c->pad, c->count, c->law ? -G : G, c->m64, c->stage, counter, c->stream));
     unsigned good = 0;
     HIP_TRY(hipMemcpyAsync(&good, counter, sizeof good, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -577,11 +589,15 @@ int nbx_ctx_energy(nbx_ctx* c, double G, double* kinetic, double* potential) {
     L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->phi; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.chunk_first = 0; L.vchunks = c->n_shards; L.chunk_skip = INT_MAX; L.splits = kPhiSlices;
     L.eps2 = (float)(c->softening * c->softening);
+    L.law = c->law;
+    if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     HIP_TRY(launch_potential(c->dim, L, c->stream));
     const size_t bytes = 2 * c->count * sizeof(double);
     rc = ensure_stage(c, bytes ? bytes : 8);
     if (rc) return rc;
-    HIP_TRY(launch_export_energy(c->phi, kPhiSlices, c->dim, c->pad, c->count, G, c->v64, c->m64, c->stage, c->stream));
+    // per-body potential = (G m / 4) phi for the reference law (U = sum_{i<j} G m m / (2 r^2)); Newtonian:
+    // U = -sum_{i<j} G m m / sqrt(r^2+eps^2), i.e. -(G m / 2) phi = (G' m / 4) phi with G' = -2 G
+    HIP_TRY(launch_export_energy(c->phi, kPhiSlices, c->dim, c->pad, c->count, c->law ? -2.0 * G : G, c->v64, c->m64, c->stage, c->stream));
     std::vector<double> host;
     try { host.resize(2 * c->count); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
     if (bytes) HIP_TRY(hipMemcpyAsync(host.data(), c->stage, bytes, hipMemcpyDeviceToHost, c->stream));

@@ -36,6 +36,7 @@ struct nbx_ctx {
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
     hipGraphExec_t step_exec = nullptr;
     double graph_G = 0.0, graph_dt = 0.0, graph_eps = 0.0;
+    int graph_law = 0;
     int graph_variant = -1, graph_splits = 0;
     hipStream_t graph_stream = nullptr;
     bool capturing = false;
@@ -47,6 +48,7 @@ struct nbx_ctx {
     bool no_graphs = false;      // NBODY_HIP_NO_GRAPHS=1: always step eagerly
     int tgt_cand_valid = 0;     // the device's candidate-target list matches the own chunk's positions
     int bad_list_pass = -1;     // NBX_SRC_* pass whose bad-target list is on the device (-1: none / stale)
+    int law = 0;                // 0: the reference's law, 1: softened Newtonian (extension; needs softening > 0)
     double softening = 0.0;     // epsilon of the softened law (0: the reference law, no softening)
     double mass_max = 0.0;      // largest |mass| seen at upload (the softened law needs m / eps^4 finite in fp32)
     bool extent_ok = false;     // every |coordinate| <= kOneRcpMaxCoord at upload (one-reciprocal kernel allowed)

@@ -86,6 +86,7 @@ struct AccelLaunch {
     int* tgt_cand_valid;      // host flag owned by the context: cand_list matches the own chunk's positions
     int* bad_list_pass;       // host flag owned by the context: pass whose bad list is current (-1: none)
     float eps2;               // > 0: softened law (fast variants only; no close-set pipeline)
+    int law;                  // 0: the reference's r^-4 d law, 1: Newtonian r^-3 d (needs eps2 > 0)
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -126,10 +127,12 @@ struct KernelVariant {
     int needs_extent;     // 1: only valid while every |coordinate| <= kOneRcpMaxCoord (one-reciprocal kernel)
     void (*soft2)(KArgs); // softened-law build of the same kernel (null: none), D = 2 / 3
     void (*soft3)(KArgs);
+    void (*newton2)(KArgs);  // softened Newtonian law (two-reciprocal form of the same kernel)
+    void (*newton3)(KArgs);
 };
 // force_kernel.hip
 const KernelVariant* kernel_variants(int* count);
-struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); };  // [0]: D=2, [1]: D=3
+struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); void (*potential_newton[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
 // force_launch.hip

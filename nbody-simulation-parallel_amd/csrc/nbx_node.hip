@@ -340,6 +340,15 @@ int nbx_node_set_softening(nbx_node* nd, double epsilon) {
     return NBX_OK;
 }
 
+int nbx_node_set_law(nbx_node* nd, int law) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        int rc = nbx_ctx_set_law(k.ctx, law);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
 int nbx_node_compute_forces(nbx_node* nd, double G, double* forces_out) {
     if (!nd || (!forces_out && nd->n_total)) return fail(NBX_ERR_INVALID, "null argument");
     if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");

@@ -39,6 +39,7 @@ struct Options {
     std::string dump;               // prefix: write bodies and each method's forces as raw doubles
     double G = ::G;                 // --G: coupling constant of the HIP stepping loop (default: the reference's)
     int energy_every = 0;           // --energy-every k: log E and |dE/E0| every k steps of the loop
+    std::string law = "reference";  // --law reference|newton: pair law of the stepping loop (newton: extension, needs --softening)
     double softening = 0.0;         // --softening eps: Plummer-softened law in the stepping loop (extension; 0 = reference law)
     std::vector<int> devices;       // --gpus / --devices: shard the HIP rows over these GPUs (one process)
 };
@@ -214,11 +215,12 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
     if (opt.steps > 0 && run_hip) {
         out << "Leapfrog (kick-drift) on HIP: " << opt.steps << " steps, dt = " << opt.dt << ", G = " << opt.G;
         if (opt.softening > 0.0) out << ", softening = " << opt.softening;
+        if (opt.law != "reference") out << ", law = " << opt.law;
         out << std::endl;
         std::vector<Body<D>> state = bodies;
         double kernel_s = 0.0;
         const long long us = safely_execute(log, "Leapfrog_HIP", [&] {
-            HipSimulation<D> sim(bodies, opt.G, opt.softening);
+            HipSimulation<D> sim(bodies, opt.G, opt.softening, opt.law == "newton");
             double ke = 0.0, pe = 0.0, e0 = 0.0;
             const int chunk = opt.energy_every > 0 ? opt.energy_every : opt.steps;
             if (opt.energy_every > 0) {
@@ -271,6 +273,8 @@ void usage(const char* argv0) {
               << "      --steps <k>     Also run k kick-drift steps on the device" << std::endl
               << "      --dt <t>        Time step for --steps (default: 1)" << std::endl
               << "      --G <value>     Coupling constant of the stepping loop (default: the reference's 4.471e-21)" << std::endl
+              << "      --law <reference|newton> Pair law of the stepping loop: the reference's r^-4 form (default) or the attractive" << std::endl
+              << "                      softened Newtonian law (extension; needs --softening; Plummer velocities then use --G)" << std::endl
               << "      --softening <eps> Plummer softening of the stepping loop's pair law (extension; default 0 = the reference's law)" << std::endl
               << "      --energy-every <k> Log total energy and |dE/E0| every k steps (potential matching the reference law)" << std::endl
               << "      --gpus <g>      Shard the HIP rows over GPUs 0..g-1 of this node (one process, RCCL all-gather per step)" << std::endl
@@ -322,6 +326,12 @@ int main(int argc, char* argv[]) {
             opt.energy_every = std::stoi(argv[++i]);
         } else if (arg == "--softening" && has_value) {
             opt.softening = std::stod(argv[++i]);
+        } else if (arg == "--law" && has_value) {
+            opt.law = argv[++i];
+            if (opt.law != "reference" && opt.law != "newton") {
+                std::cerr << "Error: --law must be reference or newton" << std::endl;
+                return 1;
+            }
         } else if (arg == "--gpus" && has_value) {
             const int g = std::stoi(argv[++i]);
             if (g < 1 || g > 64) {
@@ -363,11 +373,11 @@ int main(int argc, char* argv[]) {
     const std::string run_id = get_run_id();
     try {
         if (opt.dimension == 2) {
-            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<2>(opt.num_bodies, opt.seed)
+            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<2>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
                                                 : generate_random_bodies<2>(opt.num_bodies, opt.seed);
             run_benchmark<2>(bodies, run_id, opt);
         } else {
-            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<3>(opt.num_bodies, opt.seed)
+            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<3>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
                                                 : generate_random_bodies<3>(opt.num_bodies, opt.seed);
             run_benchmark<3>(bodies, run_id, opt);
         }

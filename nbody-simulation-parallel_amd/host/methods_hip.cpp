@@ -109,12 +109,13 @@ void leapfrog_hip_n_body(std::vector<Body<D>>& bodies, double dt, int nsteps) {
 }
 
 template <int D>
-HipSimulation<D>::HipSimulation(const std::vector<Body<D>>& bodies, double G, double softening) : G_(G) {
+HipSimulation<D>::HipSimulation(const std::vector<Body<D>>& bodies, double G, double softening, bool newton) : G_(G) {
     std::vector<int> devs = g_devices.empty() ? std::vector<int>{device_ordinal()} : g_devices;
     ranks_ = (int)devs.size();
     int rc = nbx_node_create(&node_, ranks_, devs.data(), D, bodies.size(), NBX_EXCHANGE_AUTO);
     if (!rc) rc = nbx_node_upload_bodies(node_, bodies.data(), sizeof(Body<D>));
     if (!rc && softening != 0.0) rc = nbx_node_set_softening(node_, softening);
+    if (!rc && newton) rc = nbx_node_set_law(node_, NBX_FORCE_LAW_NEWTON);
     if (rc != NBX_OK) {
         nbx_node_destroy(node_);
         node_ = nullptr;

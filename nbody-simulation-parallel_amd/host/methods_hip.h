@@ -37,7 +37,8 @@ template <int D>
 class HipSimulation {
 public:
     // softening > 0: Plummer-softened pair law (an extension, nbx_ctx_set_softening); 0 = the reference's law
-    HipSimulation(const std::vector<Body<D>>& bodies, double G, double softening = 0.0);
+    // newton = true: the attractive softened Newtonian law (nbx_ctx_set_law; needs softening > 0)
+    HipSimulation(const std::vector<Body<D>>& bodies, double G, double softening = 0.0, bool newton = false);
     ~HipSimulation();
     HipSimulation(const HipSimulation&) = delete;
     HipSimulation& operator=(const HipSimulation&) = delete;

@@ -523,3 +523,58 @@ int oracle_energy_softened(const double* bodies, size_t n, int D, double eps, do
     out[1] = pe;
     return 0;
 }
+
+/* ---- EXTENSION checker: softened Newtonian law (nbx_ctx_set_law(NBX_FORCE_LAW_NEWTON)) -----------------------
+ * NOT in the reference's brute force (parity unpinned by construction):
+ *   F_i = +(G m_i) sum_{j != i} m_j (p_j - p_i) / (r^2 + eps^2)^(3/2) ,  U = -sum_{i<j} G m_i m_j / sqrt(r^2 + eps^2). */
+int oracle_force_rows_newton(const double* bodies, size_t n, int D, double eps, const int64_t* rows, size_t nrows,
+                             double* out, double* sums) {
+    if (D != 2 && D != 3) return -1;
+    const size_t cnt = rows ? nrows : n;
+    const double e2 = eps * eps;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t r = 0; r < cnt; ++r) {
+        const size_t i = rows ? (size_t)rows[r] : r;
+        const double* pi = POS(bodies, i, D);
+        const double gmi = ORACLE_G * MASS(bodies, i, D);
+        double acc[3] = {0.0, 0.0, 0.0}, s = 0.0;
+        for (size_t j = 0; j < n; ++j) {
+            if (i == j) continue;
+            const double* pj = POS(bodies, j, D);
+            double d[3] = {0.0, 0.0, 0.0}, r2 = 0.0;
+            for (int k = 0; k < D; ++k) { d[k] = pj[k] - pi[k]; r2 += d[k] * d[k]; }
+            const double q = r2 + e2;
+            const double wgt = gmi * MASS(bodies, j, D) / (q * sqrt(q));
+            for (int k = 0; k < D; ++k) acc[k] += wgt * d[k];
+            s += wgt * sqrt(r2);
+        }
+        for (int k = 0; k < D; ++k) out[r * D + k] = acc[k];
+        if (sums) sums[r] = s;
+    }
+    return 0;
+}
+
+int oracle_energy_newton(const double* bodies, size_t n, int D, double eps, double* out) {
+    double ke = 0.0, pe = 0.0;
+    const double e2 = eps * eps;
+#pragma omp parallel for reduction(+ : ke, pe) schedule(dynamic, 64)
+    for (size_t i = 0; i < n; ++i) {
+        const double* xi = POS(bodies, i, D);
+        const double* vi = VEL(bodies, i, D);
+        const double mi = MASS(bodies, i, D);
+        double v2 = 0.0;
+        for (int k = 0; k < D; ++k) v2 += vi[k] * vi[k];
+        ke += 0.5 * mi * v2;
+        double row = 0.0;
+        for (size_t j = i + 1; j < n; ++j) {
+            const double* xj = POS(bodies, j, D);
+            double r2 = 0.0;
+            for (int k = 0; k < D; ++k) { double d = xj[k] - xi[k]; r2 += d * d; }
+            row += MASS(bodies, j, D) / sqrt(r2 + e2);
+        }
+        pe -= ORACLE_G * mi * row;
+    }
+    out[0] = ke;
+    out[1] = pe;
+    return 0;
+}

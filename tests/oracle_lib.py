@@ -115,8 +115,9 @@ class Oracle:
         return self.lib.oracle_num_threads()
 
     # ---- extension checker: softened law (nbx_ctx_set_softening); nothing in the reference to pin it to ----
-    def force_rows_softened(self, bodies, eps, rows=None):
-        """(forces, magnitude sums) of the softened law for the given rows (all bodies when rows is None)."""
+    def force_rows_softened(self, bodies, eps, rows=None, newton=False):
+        """(forces, magnitude sums) of the softened law (newton=True: the softened Newtonian law) for the given rows
+        (all bodies when rows is None)."""
         d = self._dim(bodies)
         if rows is None:
             cnt, rp = bodies.shape[0], None
@@ -124,13 +125,15 @@ class Oracle:
             rows = np.ascontiguousarray(rows, dtype=np.int64)
             cnt, rp = rows.size, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
         out, sums = np.zeros((cnt, d)), np.zeros(cnt)
-        rc = self.lib.oracle_force_rows_softened(_p(bodies), _sz(bodies.shape[0]), d, ctypes.c_double(eps), rp, _sz(cnt), _p(out), _p(sums))
+        fn = self.lib.oracle_force_rows_newton if newton else self.lib.oracle_force_rows_softened
+        rc = fn(_p(bodies), _sz(bodies.shape[0]), d, ctypes.c_double(eps), rp, _sz(cnt), _p(out), _p(sums))
         assert rc == 0
         return out, sums
 
-    def energy_softened(self, bodies, eps):
+    def energy_softened(self, bodies, eps, newton=False):
         out = np.zeros(2)
-        self.lib.oracle_energy_softened(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(eps), _p(out))
+        fn = self.lib.oracle_energy_newton if newton else self.lib.oracle_energy_softened
+        fn(_p(bodies), _sz(bodies.shape[0]), self._dim(bodies), ctypes.c_double(eps), _p(out))
         return out[0], out[1]
 
     # ---- leaf-pair direct sums (law 0 brute force, 1 tree leaf, 2 FMM P2P) ----

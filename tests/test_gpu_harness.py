@@ -126,3 +126,15 @@ def test_near_field_row_through_the_cpp_wrapper(tmp_path, oracle):
     assert_force_parity(f, oracle.leaf_pair_forces(br, leaves, 2), oracle.leaf_pair_magnitude_sums(br, leaves, 2), "near-field harness row")
     csv = glob.glob(os.path.join(tmp_path, "results", f"run_*_N_{n}_3D.csv"))[0]
     assert any(l.startswith(f"NearField_HIP,{n},3,") for l in open(csv).read().splitlines())
+
+
+def test_newton_law_through_the_harness(tmp_path):
+    """`--law newton --softening`: HipSimulation<3> with the attractive softened law; a virialised Plummer sphere keeps its
+    (negative) energy."""
+    import re
+    p = _run(tmp_path, "-N", "32768", "-m", "g", "--init", "plummer", "--seed", "3", "--law", "newton", "--softening", "3000",
+             "--G", "0.1", "--dt", "0.5", "--steps", "200", "--energy-every", "50", "--devices", "0,0")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    e0 = float(re.search(r"step 0  E = ([-0-9.eE+]+)", p.stdout).group(1))
+    drifts = [float(x) for x in re.findall(r"\|dE/E0\| = ([0-9.eE+-]+)", p.stdout)]
+    assert e0 < 0 and len(drifts) == 4 and max(drifts) < 5e-3, p.stdout[-1500:]

@@ -98,3 +98,76 @@ def test_softened_plummer_sphere_conserves_energy_over_dynamical_times(nbx):
     print(f"\nsoftened Plummer N={n}: max |dE/E0| = {worst:.3e} over 400 steps (2 t_dyn), KE/E0 at the end {ke / e0:.3f}, {ms:.1f} ms per step")
     assert ke > 0.2 * e0, "two dynamical times must convert a sizeable part of the potential energy"
     assert worst < 2e-2
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+def test_newtonian_law_matches_the_checker(nbx, oracle, dim):
+    """nbx_ctx_set_law(NEWTON): attractive, softened  F_i = +G m_i sum_j m_j d/(r^2+eps^2)^(3/2)  (extension; checker
+    restated in the oracle file, parity unpinned by construction)."""
+    n, eps = 6000, 2.0e4
+    b = oracle.generate(95 + dim, n, dim)
+    b[11, :dim] = b[10, :dim]
+    b = oracle.round_inputs_to_f32(b)
+    ref, S = oracle.force_rows_softened(b, eps, newton=True)
+    rep, _ = oracle.force_rows_softened(b, eps)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_law(nbx.FORCE_LAW_NEWTON)
+        with pytest.raises(nbx.NbxError):                      # no softening length yet
+            c.compute_accel()
+        c.set_softening(eps)
+        c.compute_accel()
+        f = c.forces(oracle.G)
+        assert_force_parity(f, ref, S, f"newton D={dim}")
+        assert (np.einsum("ij,ij->i", f, rep) < 0).mean() > 0.8     # attractive: mostly opposite to the repulsive law's force
+        ke_ref, pe_ref = oracle.energy_softened(b, eps, newton=True)
+        ke, pe = c.energy(oracle.G)
+        assert pe < 0 and abs(pe - pe_ref) <= 2e-6 * abs(pe_ref) and abs(ke - ke_ref) <= 1e-13 * ke_ref
+        c.set_law(nbx.FORCE_LAW_REFERENCE)
+        c.compute_accel()
+        assert_force_parity(c.forces(oracle.G), rep, oracle.force_rows_softened(b, eps)[1], "back to the reference law, softened")
+    with nbx.Node(n, dim, [0, 0, 0]) as node:                   # three virtual ranks: LOCAL + REMOTE passes, kick/drift sign
+        node.upload(b)
+        node.set_softening(eps)
+        node.set_law(nbx.FORCE_LAW_NEWTON)
+        assert_force_parity(node.forces(oracle.G), ref, S, f"newton, node D={dim}")
+        Gs = oracle.G * 1e22
+        node.step(2.0, 1, Gs)
+        got = b.copy()
+        node.download(got)
+    cur = b.copy()
+    oracle.update_body_velocities(cur, np.ascontiguousarray(ref * 1e22), 2.0)
+    oracle.update_body_positions(cur, 2.0)
+    dv, dv_ref = got[:, dim:2 * dim] - b[:, dim:2 * dim], cur[:, dim:2 * dim] - b[:, dim:2 * dim]
+    assert np.abs(dv_ref).max() > 1e-6 and np.allclose(dv, dv_ref, rtol=1e-4, atol=4e-6 * np.abs(dv_ref).max())
+
+
+def test_newtonian_plummer_sphere_stays_in_equilibrium(nbx):
+    """The physically meaningful form of BASELINE config 5 (`--law newton` "with Plummer softening"): a Plummer
+    sphere with velocities from its own distribution function, under the attractive softened Newtonian law, is a
+    stationary solution.  N = 262,144, a = 1e5, M = 1e12, G = 0.1 (t_dyn = sqrt(a^3/(G M)) = 100), eps = 1500, dt = 0.5,
+    400 steps = 2 t_dyn: energy conserved, virial ratio 2K/|U| stays near 1, the half-mass radius stays put."""
+    n = 1 << 18
+    G, dt, eps, a = 0.1, 0.5, 1500.0, 1.0e5
+    b = nbx.plummer_bodies(n, 3, seed=5, a=a, total_mass=1.0e12, G=G)
+    r_half0 = np.median(np.linalg.norm(b[:, :3] - 5.0e6, axis=1))
+    with nbx.Context(n, 3) as c:
+        c.upload(b)
+        c.set_softening(eps)
+        c.set_law(nbx.FORCE_LAW_NEWTON)
+        ke0, pe0 = c.energy(G)
+        e0 = ke0 + pe0
+        worst, virial = 0.0, [2 * ke0 / abs(pe0)]
+        for _ in range(8):
+            c.step(dt, 50, G)
+            ke, pe = c.energy(G)
+            worst = max(worst, abs(ke + pe - e0) / abs(e0))
+            virial.append(2 * ke / abs(pe))
+        cur = b.copy()
+        c.download(cur)
+    r_half1 = np.median(np.linalg.norm(cur[:, :3] - 5.0e6, axis=1))
+    print(f"\nNewtonian Plummer N={n}: E0 = {e0:.4e} (bound), max |dE/E0| = {worst:.3e} over 2 t_dyn, "
+          f"virial 2K/|U| {min(virial):.3f}..{max(virial):.3f}, half-mass radius {r_half0:.0f} -> {r_half1:.0f}")
+    assert e0 < 0 and worst < 2e-3
+    assert 0.9 < min(virial) and max(virial) < 1.1
+    assert abs(r_half1 - r_half0) < 0.05 * r_half0

@@ -7,6 +7,8 @@
 #   GPUS=1 STEPS=20 tools/run_config5.sh
 #   SOFTENING=600 G=1e4 tools/run_config5.sh   # physically resolved variant: softened at the inter-particle scale
 #                                              # (median nearest neighbour 1230), t_dyn = 100, 1000 steps = 5 t_dyn
+#   LAW=newton SOFTENING=600 G=0.1 tools/run_config5.sh   # the same sphere under the attractive softened Newtonian law:
+#                                              # a stationary solution (t_dyn = sqrt(a^3/(G M)) = 100), energy and virial ratio hold
 set -euo pipefail
 cd "$(dirname "$0")/.."
 GPUS="${GPUS:-8}"
@@ -14,9 +16,10 @@ STEPS="${STEPS:-1000}"
 EVERY="${EVERY:-50}"
 G="${G:-0.05}"
 SOFTENING="${SOFTENING:-0}"
+LAW="${LAW:-reference}"
 OUT="${OUT:-gpurun_out/config5_${GPUS}gpu_${STEPS}steps.log}"
 mkdir -p "$(dirname "$OUT")"
 [ -x ./nbody_sim ] || make nbody_sim
-./nbody_sim -N 4194304 -d 3 -m g --init plummer --seed 5 --G "$G" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" --gpus "$GPUS" | tee "$OUT"
+./nbody_sim -N 4194304 -d 3 -m g --init plummer --seed 5 --G "$G" --law "$LAW" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" --gpus "$GPUS" | tee "$OUT"
 grep -E "^step |Time taken|Kernel time" "$OUT" > "${OUT%.log}.summary.txt"
 echo "summary: ${OUT%.log}.summary.txt"
