@@ -229,7 +229,8 @@ def main():
     if world > 1:
         bad = system.verify_exchange(bodies)
         exchange_check = {"mismatching_values": bad, "checked_values_per_rank": int(args.dim * (N - system.layout.count)),
-                          "transport": backend}
+                          "transport": backend,
+                          "all_gather_form": "in place" if getattr(be, "inplace_gather", True) else "separate send buffer (the in-place form failed its self-check)"}
         if bad:
             sys.stderr.write(f"[bench] rank {rank}: position exchange FAILED its self-check: {bad} fp32 values differ from the "
                              f"generated bodies after one {backend} all-gather\n")

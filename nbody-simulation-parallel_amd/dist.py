@@ -52,6 +52,10 @@ class HipShardBackend:
         self._timing = False
         self._marks = []       # per step: dict of torch events (see enable_timing)
         self._cur = None
+        # RCCL all-gather in place (send buffer = this rank's chunk of the receive buffer: NCCL's in-place form).  Should a
+        # torch / RCCL build reject or mishandle the aliasing, verify_exchange switches to a separate send buffer.
+        self.inplace_gather = True
+        self._send_buf = None
 
     # -- pass timing (bench.py --gpus N): events on the streams the work really runs on --
     def enable_timing(self, on: bool = True):
@@ -123,8 +127,14 @@ class HipShardBackend:
                         self.pos_all[g].view(-1).copy_(allc[g].to(self.device, non_blocking=False))
             return "staged"
         with torch.cuda.stream(self.comm_stream):
-            return dist.all_gather_into_tensor(self.pos_all.view(-1), self.pos_all[self.layout.shard].view(-1),
-                                               group=group, async_op=True)
+            if self.inplace_gather:
+                src = self.pos_all[self.layout.shard].view(-1)
+            else:
+                if self._send_buf is None:
+                    self._send_buf = torch.empty_like(self.pos_all[self.layout.shard]).view(-1)
+                self._send_buf.copy_(self.pos_all[self.layout.shard].view(-1))
+                src = self._send_buf
+            return dist.all_gather_into_tensor(self.pos_all.view(-1), src, group=group, async_op=True)
 
     def finish_exchange(self, work):
         if work is None:
@@ -217,10 +227,25 @@ class ShardedNBody:
         offsets, cannot pass."""
         if self.layout.n_shards == 1:
             return 0
+        total = self._verify_once(bodies)
+        if total and getattr(self.be, "inplace_gather", False):
+            # the in-place all-gather did not deliver (every rank sees the same total, so every rank takes this branch):
+            # one more try with a separate send buffer before giving up
+            self.be.inplace_gather = False
+            total = self._verify_once(bodies)
+        return total
+
+    def _verify_once(self, bodies: np.ndarray) -> int:
         self.be.poison_remote_chunks()
-        work = self.be.start_exchange(self.group)
-        self.be.finish_exchange(work)
-        bad = self.be.remote_chunk_mismatches(bodies)
+        failed = 0
+        try:
+            work = self.be.start_exchange(self.group)
+            self.be.finish_exchange(work)
+            bad = self.be.remote_chunk_mismatches(bodies)
+        except RuntimeError as e:            # a collective that raises counts as one that delivered nothing
+            import sys
+            sys.stderr.write(f"[dist] rank {self.layout.shard}: position exchange raised: {e}\n")
+            bad, failed = 1, 1
         t = torch.tensor([bad], dtype=torch.int64)
         if dist.get_backend(self.group) == "nccl":
             t = t.cuda()

@@ -138,3 +138,13 @@ def test_newton_law_through_the_harness(tmp_path):
     e0 = float(re.search(r"step 0  E = ([-0-9.eE+]+)", p.stdout).group(1))
     drifts = [float(x) for x in re.findall(r"\|dE/E0\| = ([0-9.eE+-]+)", p.stdout)]
     assert e0 < 0 and len(drifts) == 4 and max(drifts) < 5e-3, p.stdout[-1500:]
+
+
+def test_run_config5_script_rehearsal(tmp_path):
+    """tools/run_config5.sh (the full 8-GPU, 1000-step run of BASELINE config 5) rehearsed small: two virtual ranks on
+    the one GPU, N = 131,072, 20 steps, energy every 10."""
+    env = dict(os.environ, N="131072", DEVICES="0,0", STEPS="20", EVERY="10", OUT=str(tmp_path / "c5.log"))
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_config5.sh")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    summary = open(tmp_path / "c5.summary.txt").read()
+    assert summary.count("|dE/E0|") == 2 and "Time taken" in summary, summary

@@ -12,6 +12,8 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 GPUS="${GPUS:-8}"
+N="${N:-4194304}"                 # BASELINE config 5's size; smaller values are for rehearsals
+DEVICES="${DEVICES:-}"            # explicit device list instead of 0..GPUS-1, e.g. 0,0 = two virtual ranks on one GPU
 STEPS="${STEPS:-1000}"
 EVERY="${EVERY:-50}"
 G="${G:-0.05}"
@@ -20,6 +22,7 @@ LAW="${LAW:-reference}"
 OUT="${OUT:-gpurun_out/config5_${GPUS}gpu_${STEPS}steps.log}"
 mkdir -p "$(dirname "$OUT")"
 [ -x ./nbody_sim ] || make nbody_sim
-./nbody_sim -N 4194304 -d 3 -m g --init plummer --seed 5 --G "$G" --law "$LAW" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" --gpus "$GPUS" | tee "$OUT"
+if [ -n "$DEVICES" ]; then where=(--devices "$DEVICES"); else where=(--gpus "$GPUS"); fi
+./nbody_sim -N "$N" -d 3 -m g --init plummer --seed 5 --G "$G" --law "$LAW" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" "${where[@]}" | tee "$OUT"
 grep -E "^step |Time taken|Kernel time" "$OUT" > "${OUT%.log}.summary.txt"
 echo "summary: ${OUT%.log}.summary.txt"
