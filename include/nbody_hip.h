@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NBX_ABI_VERSION 1
+#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange (additions only) */
 
 /* status codes */
 enum {
