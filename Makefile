@@ -26,7 +26,7 @@ DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8
 
 # -fno-slp-vectorize: the packed arithmetic is written by hand on float2 values (see force_kernel.hip)
 $(CSRC)/force_kernel.o: $(CSRC)/force_kernel.hip $(CSRC)/nbx_internal.h
-	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(FORCE_KERNEL_DEFS) -fno-slp-vectorize -c $< -o $@
 
 $(CSRC)/force_launch.o: $(CSRC)/force_launch.hip $(CSRC)/nbx_internal.h Makefile
 	$(HIPCC) $(HIPFLAGS) -DNBX_DEFAULT_VARIANT='"$(DEFAULT_VARIANT)"' -DNBX_DEFAULT_EXACT_VARIANT='"$(DEFAULT_EXACT_VARIANT)"' -c $< -o $@

@@ -300,7 +300,7 @@ def main():
         # profiles/<round>/pmc_force_kernel.json), and only if that profile is of the kernel that just ran -- otherwise the
         # field stays null and says why.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads (guide: the x2 correction
         # applies to 16-byte streaming loads), so the raw sum is reported.
-        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1>",
+        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1>",
                      "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>"}
         prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
         try:

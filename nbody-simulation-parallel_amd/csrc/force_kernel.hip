@@ -72,8 +72,8 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
 //                 launched only when every |coordinate| <= kOneRcpMaxCoord (nbx_internal.h).
 // NEWTON = 1 (softened Newtonian law, an extension): the weight is m (r^2+eps^2)^-3/2 -- v_rsq_f32 in place of v_rcp_f32
 // and one more v_pk_mul: 14 VALU per two pairs.
-template <int D, int PAIRS, int ONE_RCP, int NEWTON = 0>
-__device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, float sm, const f2 (&ix)[PAIRS],
+template <int D, int PAIRS, int ONE_RCP, int NEWTON = 0, int HI_SEL = 1>
+__device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f2 szm, const f2 (&ix)[PAIRS],
                                                  const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
                                                  f2 (&ay)[PAIRS], f2 (&az)[PAIRS], const f2 bias) {
     f2 dx[PAIRS], dy[PAIRS], dz[PAIRS], r2[PAIRS], w[PAIRS];
@@ -106,14 +106,25 @@ __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
     }
+    // weight = m * w^2 (NEWTON: m * w^3), the mass applied LAST.  The mass is the HIGH half of the source's {z, m}
+    // register pair: hipcc folds a low-half or a first-pair high-half broadcast into op_sel, but copies the 4th component
+    // of a ds_read_b128 with a v_mov_b32 per source (1 of 53 VALU per source), so the modifier is spelled out.  The
+    // inline instruction must not read a v_rcp/v_rsq result directly: the compiler's trans->VALU hazard handling (s_nop)
+    // does not see inside inline asm -- hence w^2 first (plain code, hazards handled), then the multiply by m.
 #pragma unroll
-    for (int q = 0; q < PAIRS; ++q) r2[q] = f2{sm, sm} * w[q];
+    for (int q = 0; q < PAIRS; ++q) r2[q] = w[q] * w[q];
     if (NEWTON) {
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) r2[q] = r2[q] * w[q];
     }
+    if (HI_SEL) {
 #pragma unroll
-    for (int q = 0; q < PAIRS; ++q) w[q] = r2[q] * w[q];
+        for (int q = 0; q < PAIRS; ++q)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w[q]) : "v"(szm), "v"(r2[q]));
+    } else {   // what the compiler makes of it: v_mov_b32 + low-half broadcast (kept for the A/B in profiles/r2)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) w[q] = f2{szm.y, szm.y} * r2[q];
+    }
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) ax[q] = __builtin_elementwise_fma(w[q], dx[q], ax[q]);
 #pragma unroll
@@ -249,7 +260,7 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // and there is no close set: close_blocks = 0, bad_flag is not read.
 // SOFT = 2: softened NEWTONIAN law  a_i = sum_j m_j d / (r^2 + eps^2)^(3/2)  (nbx_ctx_set_law; the `--law newton` of
 // SURVEY 5/7; attractive -- the sign is applied with G by the consumers).  Never combined with ONE_RCP.
-template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0>
+template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0, int HI_SEL = 1>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 #pragma unroll UNROLL
         for (int j = 0; j < kTile; ++j) {
             const float4 s = cur[j];
-            interact2_staged<D, PAIRS, (SOFT == 2) ? 0 : ONE_RCP, SOFT == 2>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az, bias);
+            interact2_staged<D, PAIRS, (SOFT == 2) ? 0 : ONE_RCP, SOFT == 2, HI_SEL>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
         }
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
@@ -568,6 +579,9 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
+#ifdef NBX_AB_HI_SEL
+    {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
+#endif
     {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
 };
 
