@@ -18,7 +18,7 @@ all: lib oracle nbody_sim
 lib: $(LIB)
 
 OBJS := $(CSRC)/force_kernel.o $(CSRC)/force_launch.o \
-        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o $(CSRC)/leaf_pair_kernel.o
+        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o $(CSRC)/leaf_pair_kernel.o $(CSRC)/close_hash.o
 # name of the force-kernel variant used when the caller does not pick one
 DEFAULT_VARIANT ?= fastpk_t8_w3_u4
 # exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
@@ -40,6 +40,9 @@ $(CSRC)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h 
 
 $(CSRC)/nbx_node.o: $(CSRC)/nbx_node.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h
+	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c $< -o $@
 
 $(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

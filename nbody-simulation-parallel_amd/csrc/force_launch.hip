@@ -117,12 +117,17 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
             if (L.count) {
                 hipLaunchKernelGGL(table().ck.classify_src[di], dim3(L.pad / 256u, (unsigned)L.vchunks, 1), block, 0, stream, a);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
-                hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if (L.hash.keys) {   // most bodies are candidates: sorted cells instead of candidates x candidates
+                    if ((e = hash_refine(dim, a, L.hash, stream)) != hipSuccess) return e;
+                } else {
+                    hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                }
             }
             if (L.bad_list_pass) *L.bad_list_pass = L.cacheable ? L.pass : -1;
         }
     }
+    if (L.lists_only) return hipSuccess;
     dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(L.law ? ((dim == 3) ? V.newton3 : V.newton2)

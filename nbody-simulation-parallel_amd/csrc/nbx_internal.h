@@ -56,6 +56,17 @@ constexpr double kFastMaxMass = 1.0e10;
 constexpr double kOneRcpMaxCoord = 1.0e8;
 constexpr int kCloseBlocksX = 32;          // extra workgroups per source slice that a fast launch adds for bad targets
 
+// Workspace of the sorted-cell form of the close-set refinement (close_hash.hip); all null when not in use.
+struct HashWork {
+    unsigned long long* keys = nullptr;         // [capacity] cell keys of the pass's candidate sources (~0: empty slot)
+    unsigned long long* keys_sorted = nullptr;
+    unsigned* vals = nullptr;                   // [capacity] slot in src_cand_pos
+    unsigned* vals_sorted = nullptr;
+    void* temp = nullptr;                       // hipcub radix-sort scratch
+    size_t temp_bytes = 0;
+    unsigned capacity = 0;                      // = n_chunks * pad (every body may be a candidate)
+};
+
 // How one force evaluation walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
 struct AccelLaunch {
     const float* pos_all;
@@ -87,6 +98,8 @@ struct AccelLaunch {
     int* bad_list_pass;       // host flag owned by the context: pass whose bad list is current (-1: none)
     float eps2;               // > 0: softened law (fast variants only; no close-set pipeline)
     int law;                  // 0: the reference's r^-4 d law, 1: Newtonian r^-3 d (needs eps2 > 0)
+    HashWork hash;            // non-null: refine through sorted cells instead of candidates x candidates
+    int lists_only;           // 1: build the close-set lists and return (upload-time probe of the bad-target count)
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -134,6 +147,10 @@ struct KernelVariant {
 const KernelVariant* kernel_variants(int* count);
 struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); void (*potential_newton[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
+
+// close_hash.hip
+size_t hash_temp_bytes(unsigned capacity);
+hipError_t hash_refine(int dim, const KArgs& a, const HashWork& h, hipStream_t stream);
 
 // force_launch.hip
 hipError_t launch_accel(int dim, const AccelLaunch& a, hipStream_t stream);

@@ -102,3 +102,29 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".sh", ".h", ".hip")):
                 txt = open(os.path.join(ROOT, d, f)).read()
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt, f"{d}/{f}"
+
+
+def test_leaf_pair_entry_validates_before_it_needs_a_device(nbx):
+    """nbx_leaf_pair_forces checks every index array on the host first: malformed CSR input is NBX_ERR_INVALID even on a
+    box without a GPU, a well-formed call then fails loudly with NO_DEVICE (no CPU fallback)."""
+    b = np.zeros((10, 7))
+    b[:, :3] = np.arange(30).reshape(10, 3)
+    b[:, 6] = 1.0
+    ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
+    bad = [
+        (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 2])),            # source leaf out of range
+        (np.array([0, 5, 10]), np.r_[np.arange(9), 10], np.array([0, 1, 2]), np.array([0, 1])),  # body out of range
+        (np.array([0, 5, 10]), np.r_[np.arange(9), 0], np.array([0, 1, 2]), np.array([0, 1])),   # body in two leaves
+        (np.array([0, 6, 5]), np.arange(6), np.array([0, 1, 2]), np.array([0, 1])),              # decreasing offsets
+    ]
+    for leaves in bad:
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.leaf_pair_forces_hip(b, *leaves)
+        assert e.value.status == 1, e.value          # NBX_ERR_INVALID
+    with pytest.raises(nbx.NbxError) as e:
+        nbx.leaf_pair_forces_hip(b, *ok, law=9)
+    assert e.value.status == 1
+    if _no_gpu(nbx):
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.leaf_pair_forces_hip(b, *ok)
+        assert e.value.status in (2, 3) and "no CPU fallback" in str(e.value)          # NO_DEVICE / HIP
