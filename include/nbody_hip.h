@@ -182,8 +182,9 @@ int nbx_ctx_synchronize(nbx_ctx* ctx);
  * DESIGN.md for the table).  "fast" variants drop the per-pair r^2 guard, find the targets that own a
  * pair closer than 1e-3 exactly (candidates = a coordinate below 16384 in magnitude, checked against each
  * other once per position update) and evaluate those with the guarded kernel inside the same launch, so the
- * result keeps the reference's skip semantics; when their preconditions fail (a mass above 1e10, or more than
- * 1/8 of the shard in the candidate set) the library substitutes the guarded default. */
+ * result keeps the reference's skip semantics; small-coordinate systems (more than 1/8 of the shard in the candidate set)
+ * find their close pairs through sorted cells instead; when a mass exceeds 1e10, or more than 1/8 of the shard really
+ * owns a pair closer than 1e-3, the library substitutes the guarded default. */
 int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
 /* EXTENSION (not in the reference: its brute force is unsoftened): Plummer softening of the pair law,
  *   a_i = sum_{j != i} m_j (p_j - p_i) / (r^2 + epsilon^2)^2 ,   U = sum_{i<j} G m_i m_j / (2 (r^2 + epsilon^2)),

@@ -123,6 +123,16 @@ int ensure_acc(nbx_ctx* c) {
             HIP_TRY(hipMalloc((void**)&c->src_cand_pos, (size_t)c->dim * c->n_shards * c->pad * sizeof(float)));
             c->tgt_cand_valid = 0; c->bad_list_pass = -1;
         }
+        if (c->hash_refine && !c->hash.keys) {
+            const unsigned cap = (unsigned)c->n_shards * c->pad;
+            c->hash.capacity = cap;
+            c->hash.temp_bytes = hash_temp_bytes(cap);
+            HIP_TRY(hipMalloc((void**)&c->hash.keys, (size_t)cap * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&c->hash.keys_sorted, (size_t)cap * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&c->hash.vals, (size_t)cap * sizeof(unsigned)));
+            HIP_TRY(hipMalloc((void**)&c->hash.vals_sorted, (size_t)cap * sizeof(unsigned)));
+            HIP_TRY(hipMalloc(&c->hash.temp, c->hash.temp_bytes ? c->hash.temp_bytes : 8));
+        }
         if (!(c->close_acc && c->close_splits_alloc >= c->splits)) {
             if (c->close_acc) { HIP_TRY(hipFree(c->close_acc)); c->close_acc = nullptr; }
             HIP_TRY(hipMalloc((void**)&c->close_acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
@@ -244,6 +254,11 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->counters) (void)hipFree(c->counters);
     if (c->close_acc) (void)hipFree(c->close_acc);
     if (c->src_cand_pos) (void)hipFree(c->src_cand_pos);
+    if (c->hash.keys) (void)hipFree(c->hash.keys);
+    if (c->hash.keys_sorted) (void)hipFree(c->hash.keys_sorted);
+    if (c->hash.vals) (void)hipFree(c->hash.vals);
+    if (c->hash.vals_sorted) (void)hipFree(c->hash.vals_sorted);
+    if (c->hash.temp) (void)hipFree(c->hash.temp);
     if (c->phi) (void)hipFree(c->phi);
     if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);
     if (c->bulk0) (void)hipEventDestroy(c->bulk0);
@@ -315,7 +330,11 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
             }
         }
         c->mass_max = mmax;
-        c->force_exact = !(mmax <= kFastMaxMass) || close * 8 > c->count;
+        c->force_exact = !(mmax <= kFastMaxMass);
+        // More than 1/8 of the shard in the candidate set (a small-coordinate system): the candidates x candidates check
+        // would be O(N^2); the fast path then refines through sorted cells, provided the probe below finds few enough
+        // targets that really own a close pair.
+        c->hash_refine = !c->force_exact && close * 8 > c->count;
         c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
     }
     const size_t bytes = c->n_total * stride_bytes;
@@ -331,6 +350,30 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     c->uploaded = true;
     c->have_accel = false;
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    c->probe_bad = 0;
+    if (c->hash_refine) {
+        // Probe: build the close-set lists once against ALL sources and read the number of bad targets back (this call
+        // synchronises anyway).  Too many (> 1/8 of the shard: the guarded side path would dominate) -> guarded kernel.
+        rc = ensure_acc(c);
+        if (rc) return rc;
+        if (variant_is_fast(c->variant)) {
+            AccelLaunch L = {};
+            L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
+            L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
+            L.cand_list = c->cand_list; L.cand_pos = c->cand_pos; L.bad_list = c->bad_list; L.bad_flag = c->bad_flag;
+            L.counters = c->counters; L.close_acc = c->close_acc; L.src_cand_pos = c->src_cand_pos;
+            L.n_total = c->n_total; L.shard_len = c->shard_len; L.n_chunks = c->n_shards;
+            L.pass = NBX_SRC_ALL; L.cacheable = 0; L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
+            L.chunk_skip = INT_MAX; L.chunk_first = 0; L.vchunks = c->n_shards; L.hash = c->hash; L.lists_only = 1;
+            HIP_TRY(launch_accel(c->dim, L, c->stream));
+            unsigned counts[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(counts, c->counters, sizeof counts, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->probe_bad = counts[1];
+            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+            if ((size_t)counts[1] * 8 > c->count) { c->force_exact = true; c->hash_refine = false; }
+        }
+    }
     return NBX_OK;
 }
 
@@ -399,6 +442,8 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
     L.eps2 = (float)(c->softening * c->softening);
     L.law = c->law;
+    L.lists_only = 0;
+    if (c->hash_refine && variant_is_fast(c->variant) && !(c->softening > 0.0)) L.hash = c->hash;
     if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     if (c->softening > 0.0 && !(c->mass_max / ((double)L.eps2 * (double)L.eps2) < 1.0e38))
         return fail(NBX_ERR_INVALID, "softening too small for these masses: m / eps^4 must stay finite in fp32");

@@ -32,6 +32,9 @@ struct nbx_ctx {
     float* close_acc = nullptr;
     int close_splits_alloc = 0;
     float* src_cand_pos = nullptr;   // [dim][n_shards*pad] candidate sources of the pass being launched
+    nbx::HashWork hash;              // sorted-cell refinement workspace (allocated only in hash mode)
+    bool hash_refine = false;        // most of the shard is in the candidate set: refine through sorted cells
+    unsigned probe_bad = 0;          // bad targets found by the upload-time probe (hash mode)
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
     hipGraphExec_t step_exec = nullptr;

@@ -280,15 +280,17 @@ def test_fast_path_preconditions_fall_back_to_guarded_kernel(nbx, oracle):
         assert "exact" in c.effective_tuning()[0]
         c.compute_accel()
         assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "huge mass")
-    # (2) a whole system inside the candidate region (small box): guarded kernel for everything
+    # (2) a whole system inside the candidate region (small box) no longer forces the guarded kernel: see
+    #     test_small_coordinate_systems_keep_the_fast_path (sorted-cell refinement); a system in which MOST targets really
+    #     own a sub-threshold pair still does
     b = oracle.generate(6, n, dim)
-    b[:, :3] = b[:, :3] / 1e4
+    b[:, :3] = b[:, :3] / 1e9                                   # box of 0.01: typical separations 7e-4, r^2 ~ 5e-7 and below
     b = oracle.round_inputs_to_f32(b)
     with nbx.Context(n, dim) as c:
         c.upload(b)
         assert "exact" in c.effective_tuning()[0]
         c.compute_accel()
-        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "small box")
+        assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "tiny box")
     # (3) bodies that DRIFT into the candidate region after upload stay correct (lists are rebuilt per position update)
     b = oracle.round_inputs_to_f32(oracle.generate(7, n, dim))
     b[:, 3:6] = 0.0
@@ -336,6 +338,63 @@ def test_one_reciprocal_variant_extent_precondition(nbx, oracle):
             f = c.forces(oracle.G)
         assert np.isfinite(f).all()
         assert_force_parity(f, oracle.brute_force_seq(big), oracle.force_magnitude_sums(big), f"extent x{scale:g}")
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+def test_small_coordinate_systems_keep_the_fast_path(nbx, oracle, dim):
+    """Unit-scale systems (every coordinate below 16384, so EVERY body is a close-set candidate): the fast kernel stays in
+    use, with the close pairs found through sorted cells (csrc/close_hash.hip) instead of candidates x candidates --
+    single context, graph-replayed steps, and shards with planted pairs straddling the shard boundary."""
+    import cross_shard_case as csc
+    n = 40000
+    rng = np.random.default_rng(3)
+    b = oracle.generate(60 + dim, n, dim)
+    b[:, :dim] = rng.normal(scale=1.0, size=(n, dim))          # Gaussian blob around the origin, both signs
+    L = csc.shard_len(n, 2)
+    b[100, :dim] = b[101, :dim];            b[100, 0] += 4.0e-6      # r^2 = 1.6e-11: skipped by the reference
+    b[200, :dim] = b[201, :dim];            b[200, 1] += 2.0e-4      # r^2 = 4e-8: counted, below the kTiny-bias level
+    b[300, :dim] = b[301, :dim]                                      # exact duplicates
+    b[L - 1, :dim] = b[L, :dim];            b[L - 1, 0] += 4.0e-6    # the same three kinds straddling the 2-shard boundary
+    b[L - 2, :dim] = b[L + 1, :dim];        b[L - 2, 1] += 2.0e-4
+    b[L - 3, :dim] = b[L + 2, :dim]
+    b = oracle.round_inputs_to_f32(b)
+    ref = oracle.brute_force_seq(b)
+    S = oracle.force_magnitude_sums(b)
+    special = [100, 101, 200, 201, 300, 301, L - 1, L, L - 2, L + 1, L - 3, L + 2]
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        assert c.effective_tuning()[0].startswith("fast"), c.effective_tuning()
+        c.compute_accel()
+        f = c.forces(oracle.G)
+        assert_force_parity(f, ref, S, f"small coordinates D={dim}")
+        for i in special:
+            assert np.linalg.norm(f[i] - ref[i]) <= 5e-5 * np.linalg.norm(ref[i]), (i, f[i], ref[i])
+        c.compute_accel()
+        assert np.array_equal(f, c.forces(oracle.G))
+        # stepping (graph replay from 4 steps on) rebuilds the sorted cells every step
+        Gs = oracle.G * 1e-6
+        eager, graph = b.copy(), b.copy()
+        for _ in range(6):
+            c.compute_accel()
+            c.kick_drift(1e-3, Gs)
+        c.download(eager)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.step(1e-3, 6, Gs)
+        c.download(graph)
+    assert np.array_equal(eager, graph)
+    for r in range(2):
+        with nbx.Context(n, dim, n_shards=2, shard=r) as c:
+            c.upload(b)
+            assert c.effective_tuning()[0].startswith("fast")
+            lo = r * c.shard_len
+            c.compute_accel(nbx.SRC_LOCAL)
+            c.compute_accel(nbx.SRC_REMOTE)
+            fs = c.forces(oracle.G)
+            assert_force_parity(fs, ref[lo:lo + c.count], S[lo:lo + c.count], f"small coordinates, shard {r} D={dim}")
+            for i in special:
+                if lo <= i < lo + c.count:
+                    assert np.linalg.norm(fs[i - lo] - ref[i]) <= 5e-5 * np.linalg.norm(ref[i]), (r, i)
 
 
 def test_signed_and_extreme_coordinates(nbx, oracle):
