@@ -1,10 +1,12 @@
 """CPU: host-side logic of the package that needs no GPU: the numpy body generator reproduces the
 reference generator's stream (= the oracle's = libstdc++'s), Plummer sampling is sane, the ctypes
 layer validates shapes."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import ROOT, golden
 
 
 @pytest.mark.parametrize("dim,n", [(2, 64), (3, 1024), (3, 3)])
@@ -28,3 +30,30 @@ def test_body_stride_and_shapes(nbx):
     assert nbx.body_stride(3) == 7 and nbx.body_stride(2) == 5
     with pytest.raises(ValueError):
         nbx.uniform_bodies(4, 4)
+
+
+def test_aggregate_keeps_reference_columns_and_adds_gpu_counts(tmp_path):
+    """tools/aggregate_results.py on synthetic sweep output (no GPU needed): the main table keeps the reference's four
+    columns (analysis/aggregated_results.csv:1) with BruteForce_HIP_x<G> rows; the sidecar table carries GPUs, distinct
+    devices and the kernel speed-up over the one-GPU row."""
+    import csv
+    import subprocess
+    res = tmp_path / "results"
+    res.mkdir()
+    runs = [("01012026_000001", 1000000, "BruteForce_HIP", 1, 1, 0.30, 0.21), ("01012026_000002", 1000000, "BruteForce_HIP", 1, 1, 0.32, 0.23),
+            ("01012026_000003", 1000000, "BruteForce_HIP_x2", 2, 2, 0.20, 0.11), ("01012026_000004", 1000000, "BruteForce_HIP_x8", 8, 1, 0.31, 0.22)]
+    for rid, n, label, gpus, distinct, t, k in runs:
+        (res / f"run_{rid}_N_{n}_3D.csv").write_text(f"Method,Bodies,Dimension,Time(s)\n{label},{n},3,{t:.6f}\n")
+        (res / f"run_{rid}_N_{n}_3D_hip.csv").write_text(
+            "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec,GPUs,DistinctDevices\n"
+            f"{label},{n},3,{t:.6f},{k:.6f},{n * n / k:.6e},{gpus},{distinct}\n")
+    p = subprocess.run(["python3", os.path.join(ROOT, "tools", "aggregate_results.py"), str(res)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    agg = list(csv.DictReader(open(res / "aggregated_results.csv")))
+    assert list(agg[0].keys()) == ["Bodies", "Method", "Dimension", "Average Runtime (s)"]
+    by = {r["Method"]: float(r["Average Runtime (s)"]) for r in agg}
+    assert by["BruteForce_HIP"] == pytest.approx(0.31) and set(by) == {"BruteForce_HIP", "BruteForce_HIP_x2", "BruteForce_HIP_x8"}
+    hip = {(int(r["GPUs"]), int(r["Distinct Devices"])): r for r in csv.DictReader(open(res / "aggregated_hip.csv"))}
+    assert hip[(1, 1)]["Runs"] == "2" and float(hip[(2, 2)]["Kernel Speed-up vs 1 GPU"]) == pytest.approx(0.22 / 0.11)
+    # eight virtual ranks on ONE device: the fraction of peak is priced against one GPU, not eight
+    assert float(hip[(8, 1)]["Fraction of fp32 peak of the GPUs used (20 flop/pair)"]) == pytest.approx(1e12 / 0.22 * 20 / 157.3e12, rel=1e-6)
