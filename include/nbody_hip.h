@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange (additions only) */
+#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode (additions only) */
 
 /* status codes */
 enum {
@@ -186,6 +186,17 @@ int nbx_ctx_synchronize(nbx_ctx* ctx);
  * find their close pairs through sorted cells instead; when a mass exceeds 1e10, or more than 1/8 of the shard really
  * owns a pair closer than 1e-3, the library substitutes the guarded default. */
 int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
+/* How the fast path currently keeps the reference's r^2 < 1e-10 skip rule (diagnostic):
+ *   NBX_CLOSE_CANDIDATE_PAIRS  candidate targets x candidate sources (few bodies have a coordinate below 16384)
+ *   NBX_CLOSE_SORTED_CELLS     most bodies are candidates: close pairs found through sorted cells
+ *   NBX_CLOSE_GUARDED_KERNEL   the per-pair guarded kernel runs instead (mass above 1e10, > 1/8 of the shard owning a close
+ *                              pair, or an exact variant selected)
+ *   NBX_CLOSE_NONE             softened law: nothing to guard
+ * Decided at upload and re-evaluated during long runs from an asynchronous read-back of the device counters every 16
+ * steps (never a wait).  candidates_seen / bad_seen: the most recent counts the host has seen (0 before the first). */
+enum { NBX_CLOSE_CANDIDATE_PAIRS = 0, NBX_CLOSE_SORTED_CELLS = 1, NBX_CLOSE_GUARDED_KERNEL = 2, NBX_CLOSE_NONE = 3 };
+int nbx_ctx_close_set_mode(nbx_ctx* ctx, int* mode, unsigned* candidates_seen, unsigned* bad_seen);
+
 /* EXTENSION (not in the reference: its brute force is unsoftened): Plummer softening of the pair law,
  *   a_i = sum_{j != i} m_j (p_j - p_i) / (r^2 + epsilon^2)^2 ,   U = sum_{i<j} G m_i m_j / (2 (r^2 + epsilon^2)),
  * every pair counted (no r^2 < 1e-10 skip; a body never acts on itself).  epsilon = 0 (default) is the reference law.

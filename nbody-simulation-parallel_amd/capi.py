@@ -54,6 +54,7 @@ ABI = [
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_ctx_set_softening", _i, [_vp, _d]),
     ("nbx_ctx_set_law", _i, [_vp, _i]),
+    ("nbx_ctx_close_set_mode", _i, [_vp, _pi, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
     ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
     ("nbx_num_variants", _i, []),
     ("nbx_variant_name", _c.c_char_p, [_i]),
@@ -239,6 +240,12 @@ class Context:
     def set_softening(self, epsilon: float):
         """Extension: Plummer-softened pair law (epsilon = 0 restores the reference's unsoftened law)."""
         self._ck(self.lib.nbx_ctx_set_softening(self.h, float(epsilon)), "nbx_ctx_set_softening")
+
+    def close_set_mode(self) -> Tuple[str, int, int]:
+        """(mode, candidates seen, bad targets seen): how the fast path currently keeps the reference's skip rule."""
+        m, a, b = ctypes.c_int(0), ctypes.c_uint(0), ctypes.c_uint(0)
+        self._ck(self.lib.nbx_ctx_close_set_mode(self.h, ctypes.byref(m), ctypes.byref(a), ctypes.byref(b)), "nbx_ctx_close_set_mode")
+        return ("candidate_pairs", "sorted_cells", "guarded_kernel", "none")[m.value], a.value, b.value
 
     def set_law(self, law: int):
         """Extension: FORCE_LAW_REFERENCE (default) or FORCE_LAW_NEWTON (attractive, softened; needs set_softening > 0)."""

@@ -142,6 +142,37 @@ int ensure_acc(nbx_ctx* c) {
     return NBX_OK;
 }
 
+constexpr int kPollEverySteps = 16;
+
+// Long runs: the refinement mode and the 1/8 bad-target limit are decided at upload, but bodies move.  Every
+// kPollEverySteps steps the three close-set counters are copied to pinned host memory asynchronously; whenever a copy has
+// landed (event query, never a wait) the host re-evaluates: many candidates -> sorted cells, few again -> candidates x
+// candidates, too many targets that really own a close pair -> the guarded kernel.
+int poll_close_counters(nbx_ctx* c, int steps) {
+    if (c->capturing || c->softening > 0.0 || c->force_exact || !c->counters || !variant_is_fast(c->variant)) return NBX_OK;
+    if (c->counters_pending && hipEventQuery(c->counters_ev) == hipSuccess) {
+        c->counters_pending = false;
+        c->last_cand = c->counters_host[0];
+        c->last_bad = c->counters_host[1];
+        if ((size_t)c->last_bad * 8 > c->count) { c->force_exact = true; c->hash_refine = false; }
+        else if (!c->hash_refine && (size_t)c->last_cand * 8 > c->count) c->hash_refine = true;
+        else if (c->hash_refine && (size_t)c->last_cand * 16 < c->count) c->hash_refine = false;   // hysteresis
+    }
+    (void)hipGetLastError();   // hipEventQuery leaves hipErrorNotReady behind
+    c->steps_since_poll += steps;
+    if (!c->counters_pending && c->steps_since_poll >= kPollEverySteps) {
+        if (!c->counters_host) {
+            HIP_TRY(hipHostMalloc((void**)&c->counters_host, 4 * sizeof(unsigned), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&c->counters_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(c->counters_host, c->counters, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->counters_ev, c->stream));
+        c->counters_pending = true;
+        c->steps_since_poll = 0;
+    }
+    return NBX_OK;
+}
+
 int set_device(const nbx_ctx* c) {
     (void)hipGetLastError();  // launches are checked with hipGetLastError(): start from a clean slate
     HIP_TRY(hipSetDevice(c->device));
@@ -259,6 +290,8 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->hash.vals) (void)hipFree(c->hash.vals);
     if (c->hash.vals_sorted) (void)hipFree(c->hash.vals_sorted);
     if (c->hash.temp) (void)hipFree(c->hash.temp);
+    if (c->counters_host) (void)hipHostFree(c->counters_host);
+    if (c->counters_ev) (void)hipEventDestroy(c->counters_ev);
     if (c->phi) (void)hipFree(c->phi);
     if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);
     if (c->bulk0) (void)hipEventDestroy(c->bulk0);
@@ -351,6 +384,7 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     c->have_accel = false;
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     c->probe_bad = 0;
+    c->counters_pending = false; c->steps_since_poll = 0; c->last_cand = c->last_bad = 0;
     if (c->hash_refine) {
         // Probe: build the close-set lists once against ALL sources and read the number of bad targets back (this call
         // synchronises anyway).  Too many (> 1/8 of the shard: the guarded side path would dominate) -> guarded kernel.
@@ -396,6 +430,16 @@ int nbx_ctx_set_softening(nbx_ctx* c, double epsilon) {
     c->softening = epsilon;
     c->have_accel = false;
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    return NBX_OK;
+}
+
+int nbx_ctx_close_set_mode(nbx_ctx* c, int* mode, unsigned* candidates_seen, unsigned* bad_seen) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    const int v = effective_variant(c);
+    if (mode) *mode = (c->softening > 0.0) ? NBX_CLOSE_NONE : !variant_is_fast(v) ? NBX_CLOSE_GUARDED_KERNEL
+                      : c->hash_refine ? NBX_CLOSE_SORTED_CELLS : NBX_CLOSE_CANDIDATE_PAIRS;
+    if (candidates_seen) *candidates_seen = c->last_cand;
+    if (bad_seen) *bad_seen = c->last_bad ? c->last_bad : c->probe_bad;
     return NBX_OK;
 }
 
@@ -487,6 +531,8 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
     k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = c->law ? -G : G; k.dt = dt;
     k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64;
     k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
+    rc = poll_close_counters(c, 1);   // before the lists are invalidated on the host side: the counters belong to this step
+    if (rc) return rc;
     HIP_TRY(launch_kick_drift(k, c->stream));
     c->have_accel = false;
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;  // positions moved
@@ -499,7 +545,7 @@ namespace {
 // about capture is unavailable; the caller then steps eagerly.
 bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
-        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law)
+        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law && c->graph_hash == c->hash_refine)
         return true;
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -514,7 +560,7 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     const hipError_t ei = hipGraphInstantiate(&c->step_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
-    c->graph_eps = c->softening; c->graph_law = c->law;
+    c->graph_eps = c->softening; c->graph_law = c->law; c->graph_hash = c->hash_refine;
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }
@@ -545,6 +591,8 @@ int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
             c->bulk_steps = nsteps;
             c->have_accel = false;
             c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+            rc = poll_close_counters(c, nsteps);
+            if (rc) return rc;
         }
     }
     for (; s < nsteps; ++s) {

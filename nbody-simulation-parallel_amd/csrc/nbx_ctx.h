@@ -35,11 +35,18 @@ struct nbx_ctx {
     nbx::HashWork hash;              // sorted-cell refinement workspace (allocated only in hash mode)
     bool hash_refine = false;        // most of the shard is in the candidate set: refine through sorted cells
     unsigned probe_bad = 0;          // bad targets found by the upload-time probe (hash mode)
+    // periodic, asynchronous look at the close-set counters during long runs (never blocks: event query)
+    unsigned* counters_host = nullptr;   // pinned [4]
+    hipEvent_t counters_ev = nullptr;
+    bool counters_pending = false;
+    int steps_since_poll = 0;
+    unsigned last_cand = 0, last_bad = 0;   // most recent counts seen by the host
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
     hipGraphExec_t step_exec = nullptr;
     double graph_G = 0.0, graph_dt = 0.0, graph_eps = 0.0;
     int graph_law = 0;
+    bool graph_hash = false;
     int graph_variant = -1, graph_splits = 0;
     hipStream_t graph_stream = nullptr;
     bool capturing = false;

@@ -511,3 +511,39 @@ def test_device_side_accuracy_metric(nbx, oracle):
             c.compute_accel()
             lo = r * c.shard_len
             assert c.accuracy(ref[lo:lo + c.count], oracle.G) == 100.0
+
+
+def test_close_set_mode_follows_the_bodies_during_a_run(nbx, oracle):
+    """The refinement mode is chosen at upload and re-evaluated during a run from an asynchronous read-back of the device
+    counters every 16 steps: a cloud that flies from outside the candidate region (all |coordinates| > 16384) through a
+    compact state around the origin and out again goes candidate_pairs -> sorted_cells -> candidate_pairs, with forces
+    matching the oracle in every state."""
+    n, dim, dt = 20000, 3, 1.0
+    rng = np.random.default_rng(9)
+    b = oracle.generate(70, n, dim)
+    p0 = rng.uniform(20000.0, 30000.0, size=(n, dim))
+    target = rng.normal(scale=100.0, size=(n, dim))
+    b[:, :dim] = p0
+    b[:, dim:2 * dim] = (target - p0) / 20.0                    # ballistic: at the target after 20 steps, gone after ~40
+    b = oracle.round_inputs_to_f32(b)
+    G = oracle.G * 1e-12                                         # forces far too weak to bend the flight
+    seen = []
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        assert c.close_set_mode()[0] == "candidate_pairs"
+        for step in range(1, 57):
+            c.compute_accel()
+            if step in (1, 20, 56):
+                cur = b.copy()
+                c.download(cur)
+                cr = oracle.round_inputs_to_f32(cur)
+                assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(cr), oracle.force_magnitude_sums(cr), f"step {step}")
+                c.compute_accel()
+            c.kick_drift(dt, G)
+            c.synchronize()                                      # lets the pending counter copy land before the next poll
+            seen.append(c.close_set_mode())
+    modes = [m for m, _, _ in seen]
+    assert modes[10] == "candidate_pairs"                        # polled at step 16 at the earliest
+    assert "sorted_cells" in modes[17:34], modes
+    assert modes[-1] == "candidate_pairs", seen[-5:]
+    assert max(cand for _, cand, _ in seen) == n                 # the poll at step 16 saw every body in the candidate set
