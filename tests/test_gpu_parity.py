@@ -547,3 +547,58 @@ def test_close_set_mode_follows_the_bodies_during_a_run(nbx, oracle):
     assert "sorted_cells" in modes[17:34], modes
     assert modes[-1] == "candidate_pairs", seen[-5:]
     assert max(cand for _, cand, _ in seen) == n                 # the poll at step 16 saw every body in the candidate set
+
+
+def test_fuzz_fast_path_against_guarded_kernel(nbx, oracle):
+    """Randomised inputs over twelve decades of coordinate scale, offsets, clusters, duplicates, sub-threshold pairs, 1-4
+    shards, D = 2 and 3: the default path (fast kernel + whichever close-set mode the library picks) against the oracle,
+    and against the guarded kernel on the same device (which never takes the close-set pipeline)."""
+    rng = np.random.default_rng(2026)
+    exact = [i for i, v in enumerate(nbx.variants()) if "exact" in v][0]
+    modes = set()
+    for case in range(36):
+        dim = 3 if case % 3 else 2
+        n = int(rng.integers(1500, 6000))
+        scale = 10.0 ** rng.uniform(-2, 7)
+        offset = rng.choice([0.0, 0.0, scale * 3.0, -scale * 10.0])
+        b = oracle.generate(1000 + case, n, dim)
+        kind = case % 4
+        if kind == 0:
+            b[:, :dim] = rng.uniform(-scale, scale, size=(n, dim)) + offset
+        elif kind == 1:
+            b[:, :dim] = rng.normal(scale=scale, size=(n, dim)) + offset
+        elif kind == 2:
+            centres = rng.uniform(-scale, scale, size=(5, dim))
+            b[:, :dim] = centres[rng.integers(0, 5, n)] + rng.normal(scale=scale * 1e-3, size=(n, dim)) + offset
+        else:
+            b[:, :dim] = np.round(rng.uniform(-scale, scale, size=(n, dim)) / (scale / 8.0)) * (scale / 8.0) + offset   # lattice: many duplicates
+        k = int(rng.integers(0, 6))                              # plant a few close pairs of every kind
+        for j in range(k):
+            i0, i1 = rng.integers(0, n, 2)
+            if i0 == i1:
+                continue
+            b[i1, :dim] = b[i0, :dim]
+            b[i1, int(rng.integers(0, dim))] += float(rng.choice([0.0, 3e-6, 2e-5, 3e-4, 2e-3]))
+        b = oracle.round_inputs_to_f32(b)
+        ref = oracle.brute_force_seq(b)
+        S = oracle.force_magnitude_sums(b)
+        G_ = int(rng.integers(1, 5))
+        parts, parts_exact = [], []
+        for r in range(G_):
+            with nbx.Context(n, dim, n_shards=G_, shard=r) as c:
+                c.upload(b)
+                modes.add(c.close_set_mode()[0])
+                if G_ == 1:
+                    c.compute_accel()
+                else:
+                    c.compute_accel(nbx.SRC_LOCAL)
+                    c.compute_accel(nbx.SRC_REMOTE)
+                parts.append(c.forces(oracle.G))
+                c.set_tuning(0, exact)
+                c.compute_accel()
+                parts_exact.append(c.forces(oracle.G))
+        f, fe = np.concatenate(parts), np.concatenate(parts_exact)
+        what = f"case {case}: D={dim} n={n} scale={scale:.1e} offset={offset:.1e} kind={kind} shards={G_}"
+        assert_force_parity(fe, ref, S, what + " [guarded kernel]")
+        assert_force_parity(f, ref, S, what + " [default path]")
+    assert {"candidate_pairs", "sorted_cells"} <= modes, modes    # the fuzz really visited both refinement modes
