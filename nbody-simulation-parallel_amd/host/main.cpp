@@ -276,7 +276,7 @@ void usage(const char* argv0) {
               << "      --law <reference|newton> Pair law of the stepping loop: the reference's r^-4 form (default) or the attractive" << std::endl
               << "                      softened Newtonian law (extension; needs --softening; Plummer velocities then use --G)" << std::endl
               << "      --softening <eps> Plummer softening of the stepping loop's pair law (extension; default 0 = the reference's law)" << std::endl
-              << "      --energy-every <k> Log total energy and |dE/E0| every k steps (potential matching the reference law)" << std::endl
+              << "      --energy-every <k> Log total energy and |dE/E0| every k steps (potential matching the selected law)" << std::endl
               << "      --gpus <g>      Shard the HIP rows over GPUs 0..g-1 of this node (one process, RCCL all-gather per step)" << std::endl
               << "      --devices <list> Same with an explicit device list, e.g. 0,0,0 = three virtual ranks on GPU 0" << std::endl
               << "      --device-count  Print the number of HIP devices and exit" << std::endl
