@@ -41,15 +41,21 @@ def main():
     out2 = os.path.join(d, "aggregated_hip.csv")
     with open(out2, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Bodies", "Dimension", "GPUs", "Distinct Devices", "Runs", "Average Runtime (s)", "Average Kernel Time (s)",
-                    "Pair Interactions/s (kernel)", "Fraction of fp32 peak of the GPUs used (20 flop/pair)", "Kernel Speed-up vs 1 GPU"])
+        w.writerow(["Bodies", "Dimension", "GPUs", "Distinct Devices", "Virtual Ranks", "Runs", "Average Runtime (s)",
+                    "Average Kernel Time (s)", "Pair Interactions/s (kernel)", "Fraction of fp32 peak of the GPUs used (20 flop/pair)",
+                    "Kernel Speed-up vs 1 GPU"])
         for (n, dim, g, dd), rows in sorted(hip.items()):
             k = len(rows)
             rate = sum(r[2] for r in rows) / k
             kern = sum(r[1] for r in rows) / k
             base = one_gpu.get((n, dim))
-            w.writerow([n, dim, g, dd, k, sum(r[0] for r in rows) / k, kern, rate, rate * 20 / (157.3e12 * dd),
-                        base / kern if base and kern > 0 else ""])
+            # Ranks that share a device ("virtual ranks": the sharded code path rehearsed on fewer GPUs) time-slice that device:
+            # their per-rank kernel time is no per-GPU figure, so rate, fraction of peak and speed-up are left to the
+            # whole-call runtime column for those rows.
+            virtual = dd < g
+            w.writerow([n, dim, g, dd, "yes" if virtual else "no", k, sum(r[0] for r in rows) / k, "" if virtual else kern,
+                        "" if virtual else rate, "" if virtual else rate * 20 / (157.3e12 * dd),
+                        "" if virtual or not (base and kern > 0) else base / kern])
     print(f"wrote {out} ({len(runs)} rows) and {out2} ({len(hip)} rows)")
 
 
