@@ -161,6 +161,8 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                 const double pairs = static_cast<double>(n) * static_cast<double>(n);
                 out << "Kernel time: " << kernel_s << " s  (" << pairs / kernel_s << " pair-interactions/s, "
                     << 100.0 * pairs * 20.0 / kernel_s / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
+                if (distinct_devices < hip_ranks)
+                    out << "  (" << hip_ranks << " ranks share " << distinct_devices << " device(s): the per-rank kernel time above is no per-GPU figure)" << std::endl;
                 hipcsv.open(base + "_hip.csv");
                 hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec,GPUs,DistinctDevices" << std::endl
                        << method.label << "," << n << "," << D << "," << std::fixed << std::setprecision(6) << seconds << ","
