@@ -237,7 +237,8 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                 if (opt.energy_every > 0) {
                     sim.energy(ke, pe);
                     out << "step " << done << "  E = " << std::setprecision(12) << ke + pe << "  |dE/E0| = " << std::setprecision(3)
-                        << std::abs((ke + pe - e0) / e0) << std::setprecision(6) << std::endl;
+                        << std::abs((ke + pe - e0) / e0) << std::setprecision(6) << "  (kinetic " << ke << ", potential " << pe
+                        << ", 2K/|U| " << 2.0 * ke / std::abs(pe) << ")" << std::endl;
                 }
             }
             sim.download(state);
