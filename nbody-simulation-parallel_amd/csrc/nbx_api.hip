@@ -685,18 +685,19 @@ int nbx_ctx_energy(nbx_ctx* c, double G, double* kinetic, double* potential) {
     L.law = c->law;
     if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     HIP_TRY(launch_potential(c->dim, L, c->stream));
-    const size_t bytes = 2 * c->count * sizeof(double);
+    const size_t nblk = (c->count + 255) / 256;
+    const size_t bytes = 2 * nblk * sizeof(double);
     rc = ensure_stage(c, bytes ? bytes : 8);
     if (rc) return rc;
     // per-body potential = (G m / 4) phi for the reference law (U = sum_{i<j} G m m / (2 r^2)); Newtonian:
     // U = -sum_{i<j} G m m / sqrt(r^2+eps^2), i.e. -(G m / 2) phi = (G' m / 4) phi with G' = -2 G
     HIP_TRY(launch_export_energy(c->phi, kPhiSlices, c->dim, c->pad, c->count, c->law ? -2.0 * G : G, c->v64, c->m64, c->stage, c->stream));
     std::vector<double> host;
-    try { host.resize(2 * c->count); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
+    try { host.resize(2 * nblk); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
     if (bytes) HIP_TRY(hipMemcpyAsync(host.data(), c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    long double ke = 0.0L, pe = 0.0L;  // body order: deterministic
-    for (size_t l = 0; l < c->count; ++l) { ke += host[l]; pe += host[c->count + l]; }
+    long double ke = 0.0L, pe = 0.0L;  // workgroup order over the device's per-workgroup sums: a fixed tree, deterministic
+    for (size_t l = 0; l < nblk; ++l) { ke += host[l]; pe += host[nblk + l]; }
     *kinetic = (double)ke;
     *potential = (double)pe;
     return NBX_OK;

@@ -200,7 +200,8 @@ hipError_t launch_export_forces(const float* acc, int splits, int dim, unsigned 
 // accel_out: SoA float[dim][count] on the device (splits summed in fp64, rounded once)
 hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned pad, size_t count,
                                float* accel_out, hipStream_t stream);
-// energy_out: double[2][count]: per-body kinetic m v^2 / 2 and potential (G m / 4) * sum_slices phi
+// energy_out: double[2][ceil(count/256)]: per-workgroup sums (wave-level reduction on the device) of the bodies' kinetic
+// m v^2 / 2 and potential (G m / 4) * sum_slices phi
 hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned pad, size_t count, double G,
                                 const double* v64, const double* m64, double* energy_out, hipStream_t stream);
 // *accurate = number of bodies whose force is within the reference's 1 % rule of ref_forces (device AoS double[count][dim])
