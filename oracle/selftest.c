@@ -18,6 +18,12 @@ int oracle_generate_random_bodies(uint32_t, size_t, int, double*);
 double oracle_compute_accuracy(const double*, const double*, size_t, int);
 void oracle_round_inputs_to_f32(double*, size_t, int);
 int oracle_energy(const double*, size_t, int, double*);
+int oracle_leaf_pair_forces(const double*, size_t, int, const uint32_t*, const uint32_t*, size_t, const uint32_t*, const uint32_t*, int, double*);
+int oracle_leaf_pair_magnitude_sums(const double*, size_t, int, const uint32_t*, const uint32_t*, size_t, const uint32_t*, const uint32_t*, int, double*);
+int oracle_force_rows_softened(const double*, size_t, int, double, const int64_t*, size_t, double*, double*);
+int oracle_force_rows_newton(const double*, size_t, int, double, const int64_t*, size_t, double*, double*);
+int oracle_energy_softened(const double*, size_t, int, double, double*);
+int oracle_energy_newton(const double*, size_t, int, double, double*);
 
 int main(void) {
     const size_t sizes[] = {0, 1, 2, 3, 17, 257};
@@ -42,7 +48,22 @@ int main(void) {
             double e[2];
             oracle_energy(b, n, D, e);
             if (n > 1 && !(isfinite(e[0]) && isfinite(e[1]))) return 7;
-            free(b); free(f); free(g); free(rows);
+            /* extension checkers: softened / Newtonian rows (all bodies and a row subset) and energies */
+            double* sums = malloc((n + 1) * sizeof(double));
+            if (!sums) return 2;
+            if (oracle_force_rows_softened(b, n, D, 0.5, NULL, 0, g, sums) || oracle_force_rows_newton(b, n, D, 0.5, rows, n, g, NULL)) return 8;
+            oracle_energy_softened(b, n, D, 0.5, e);
+            oracle_energy_newton(b, n, D, 0.5, e);
+            /* leaf-pair sums: three leaves (one empty, ragged sizes), lists with a repeated and an empty entry, every law */
+            uint32_t* lb = malloc((n + 1) * sizeof(uint32_t));
+            if (!lb) return 2;
+            for (size_t i = 0; i < n; ++i) lb[i] = (uint32_t)(n - 1 - i);
+            const uint32_t lo[4] = {0, (uint32_t)(n / 3), (uint32_t)(n / 3), (uint32_t)n};
+            const uint32_t so[4] = {0, 3, 3, 5};
+            const uint32_t ss[5] = {0, 2, 0, 2, 1};
+            for (int law = 0; law < 3; ++law)
+                if (oracle_leaf_pair_forces(b, n, D, lo, lb, 3, so, ss, law, g) || oracle_leaf_pair_magnitude_sums(b, n, D, lo, lb, 3, so, ss, law, sums)) return 9;
+            free(b); free(f); free(g); free(rows); free(sums); free(lb);
         }
     puts("oracle selftest ok");
     return 0;
