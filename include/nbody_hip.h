@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode (additions only) */
+#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk (additions only) */
 
 /* status codes */
 enum {
@@ -144,12 +144,20 @@ int nbx_ctx_compute_accel(nbx_ctx* ctx, int which);
  *   F = -(G m) a;  v += (F / m) * dt;  x += v * dt;
  * and refresh of this shard's fp32 chunk of pos_all.  Asynchronous on the context's stream. */
 int nbx_ctx_kick_drift(nbx_ctx* ctx, double G, double dt);
+/* The same kernel with separate steps for the two helpers:  v += (F / m) * dt_kick;  x += v * dt_drift.
+ * dt_drift = 0 is a pure kick (update_body_velocities alone): positions, accelerations and close-set lists stay valid. */
+int nbx_ctx_kick_drift2(nbx_ctx* ctx, double G, double dt_kick, double dt_drift);
 
 /* nsteps x { compute_accel(ALL); kick_drift } -- single-shard contexts only (n_shards == 1).  From 4 steps
  * on, one step is captured into a hipGraph and replayed (launch-bound regime at small N); nbx_ctx_kernel_time
  * then reports those steps by their whole-step time (one event pair around the replay sequence).
  * NBODY_HIP_NO_GRAPHS=1 disables the capture. */
 int nbx_ctx_step(nbx_ctx* ctx, double G, double dt, int nsteps);
+/* EXTENSION: the same two helpers composed as a synchronised kick-drift-kick leapfrog (second order in dt):
+ *   v += (F/m) dt/2;  x += v dt;  F = forces(x);  v += (F/m) dt/2      per step,
+ * with adjacent half-kicks merged: nsteps + 1 force evaluations for nsteps steps.  Single-shard contexts only; the
+ * sharded form is nbx_node_step_kdk.  (nbx_ctx_step is the reference helpers' plain order, kick then drift: first order.) */
+int nbx_ctx_step_kdk(nbx_ctx* ctx, double G, double dt, int nsteps);
 
 /* Forces of this shard's targets as Vector<dim>[shard_len] doubles: F_i = -(G m_i) a_i.
  * Synchronises the stream. */
@@ -251,6 +259,7 @@ int nbx_node_set_law(nbx_node* node, int law);                /* nbx_ctx_set_law
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
 /* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */
 int nbx_node_step(nbx_node* node, double G, double dt, int nsteps);
+int nbx_node_step_kdk(nbx_node* node, double G, double dt, int nsteps);   /* kick-drift-kick form, see nbx_ctx_step_kdk */
 int nbx_node_synchronize(nbx_node* node);
 int nbx_node_download_bodies(nbx_node* node, void* bodies, size_t body_stride_bytes);
 int nbx_node_energy(nbx_node* node, double G, double* kinetic, double* potential);

@@ -44,6 +44,8 @@ ABI = [
     ("nbx_ctx_upload_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_ctx_compute_accel", _i, [_vp, _i]),
     ("nbx_ctx_kick_drift", _i, [_vp, _d, _d]),
+    ("nbx_ctx_kick_drift2", _i, [_vp, _d, _d, _d]),
+    ("nbx_ctx_step_kdk", _i, [_vp, _d, _d, _i]),
     ("nbx_ctx_step", _i, [_vp, _d, _d, _i]),
     ("nbx_ctx_get_forces", _i, [_vp, _d, _vp]),
     ("nbx_ctx_accuracy", _i, [_vp, _d, _vp, _pd]),
@@ -70,6 +72,7 @@ ABI = [
     ("nbx_node_set_law", _i, [_vp, _i]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
+    ("nbx_node_step_kdk", _i, [_vp, _d, _d, _i]),
     ("nbx_node_synchronize", _i, [_vp]),
     ("nbx_node_download_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_node_energy", _i, [_vp, _d, _pd, _pd]),
@@ -268,6 +271,13 @@ class Context:
     def kick_drift(self, dt: float, G: float = REFERENCE_G):
         self._ck(self.lib.nbx_ctx_kick_drift(self.h, G, dt), "nbx_ctx_kick_drift")
 
+    def kick_drift2(self, dt_kick: float, dt_drift: float, G: float = REFERENCE_G):
+        self._ck(self.lib.nbx_ctx_kick_drift2(self.h, G, dt_kick, dt_drift), "nbx_ctx_kick_drift2")
+
+    def step_kdk(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
+        """Extension: synchronised kick-drift-kick leapfrog (second order) from the same two helpers."""
+        self._ck(self.lib.nbx_ctx_step_kdk(self.h, G, dt, nsteps), "nbx_ctx_step_kdk")
+
     def step(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
         self._ck(self.lib.nbx_ctx_step(self.h, G, dt, nsteps), "nbx_ctx_step")
 
@@ -372,6 +382,9 @@ class Node:
         out = np.empty((self.n_total, self.dim), dtype=np.float64)
         self._ck(self.lib.nbx_node_compute_forces(self.h, G, out.ctypes.data), "nbx_node_compute_forces")
         return out
+
+    def step_kdk(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
+        self._ck(self.lib.nbx_node_step_kdk(self.h, G, dt, nsteps), "nbx_node_step_kdk")
 
     def step(self, dt: float, nsteps: int = 1, G: float = REFERENCE_G):
         self._ck(self.lib.nbx_node_step(self.h, G, dt, nsteps), "nbx_node_step")

@@ -521,23 +521,30 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     return NBX_OK;
 }
 
-int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) {
+int nbx_ctx_kick_drift2(nbx_ctx* c, double G, double dt_kick, double dt_drift) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
     if (!c->have_accel) return fail(NBX_ERR_STATE, "compute accelerations before kick_drift");
     int rc = set_device(c);
     if (rc) return rc;
     KickDriftArgs k;
     // attractive (Newtonian) law: F = +(G m) a.  The kernels compute F = -(G m) a, so G goes in negated (exact in fp64).
-    k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = c->law ? -G : G; k.dt = dt;
+    k.acc = c->acc; k.splits = c->splits; k.dim = c->dim; k.pad = c->pad; k.count = c->count; k.G = c->law ? -G : G;
+    k.dt_kick = dt_kick; k.dt_drift = dt_drift;
     k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64;
     k.pos_chunk = c->pos_all + (size_t)c->shard * c->dim * c->pad;
-    rc = poll_close_counters(c, 1);   // before the lists are invalidated on the host side: the counters belong to this step
-    if (rc) return rc;
+    if (dt_drift != 0.0) {
+        rc = poll_close_counters(c, 1);   // before the lists are invalidated on the host side: the counters belong to this step
+        if (rc) return rc;
+    }
     HIP_TRY(launch_kick_drift(k, c->stream));
-    c->have_accel = false;
-    c->tgt_cand_valid = 0; c->bad_list_pass = -1;  // positions moved
+    if (dt_drift != 0.0) {               // a pure kick leaves the positions -- and with them accelerations and lists -- valid
+        c->have_accel = false;
+        c->tgt_cand_valid = 0; c->bad_list_pass = -1;  // positions moved
+    }
     return NBX_OK;
 }
+
+int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) { return nbx_ctx_kick_drift2(c, G, dt, dt); }
 
 namespace {
 // Capture one step on the context's stream into an executable graph (launch-bound regime: seven
@@ -602,6 +609,22 @@ int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
         if (rc) return rc;
     }
     return NBX_OK;
+}
+
+int nbx_ctx_step_kdk(nbx_ctx* c, double G, double dt, int nsteps) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (c->n_shards != 1) return fail(NBX_ERR_STATE, "nbx_ctx_step_kdk drives single-shard contexts only");
+    if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps < 0");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies before stepping");
+    if (nsteps == 0) return NBX_OK;
+    // K(dt/2) D(dt) [F K(dt) D(dt)]^(n-1) F K(dt/2): adjacent half-kicks merged, n + 1 force evaluations for n steps
+    int rc = c->have_accel ? NBX_OK : nbx_ctx_compute_accel(c, NBX_SRC_ALL);
+    for (int s = 0; s < nsteps && !rc; ++s) {
+        rc = nbx_ctx_kick_drift2(c, G, s == 0 ? 0.5 * dt : dt, dt);
+        if (!rc) rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
+    }
+    if (!rc) rc = nbx_ctx_kick_drift2(c, G, 0.5 * dt, 0.0);
+    return rc;
 }
 
 int nbx_ctx_get_forces(nbx_ctx* c, double G, double* out) {

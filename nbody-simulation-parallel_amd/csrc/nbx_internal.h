@@ -188,7 +188,7 @@ struct KickDriftArgs {
     int splits, dim;
     unsigned pad;
     size_t count;          // real bodies in this shard
-    double G, dt;
+    double G, dt_kick, dt_drift;   // v += (F/m) * dt_kick;  x += v * dt_drift  (both = dt: the reference's kick then drift)
     double* x64; double* v64; const double* m64;
     float* pos_chunk;      // this shard's chunk of pos_all: [dim][pad]
 };

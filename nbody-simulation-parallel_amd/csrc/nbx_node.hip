@@ -382,6 +382,29 @@ int nbx_node_step(nbx_node* nd, double G, double dt, int nsteps) {
     return NBX_OK;
 }
 
+int nbx_node_step_kdk(nbx_node* nd, double G, double dt, int nsteps) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps < 0");
+    if (nsteps == 0) return NBX_OK;
+    // K(dt/2) D(dt) [F K(dt) D(dt)]^(n-1) F K(dt/2) on every rank (see nbx_ctx_step_kdk)
+    int rc = evaluate(nd);
+    for (int s = 0; s < nsteps && !rc; ++s) {
+        for (Rank& k : nd->ranks) {
+            rc = nbx_ctx_kick_drift2(k.ctx, G, s == 0 ? 0.5 * dt : dt, dt);
+            if (rc) return rc;
+        }
+        rc = mark_ready(nd);
+        if (!rc) rc = evaluate(nd);
+    }
+    if (rc) return rc;
+    for (Rank& k : nd->ranks) {
+        rc = nbx_ctx_kick_drift2(k.ctx, G, 0.5 * dt, 0.0);
+        if (rc) return rc;
+    }
+    return mark_ready(nd);
+}
+
 int nbx_node_synchronize(nbx_node* nd) {
     if (!nd) return fail(NBX_ERR_INVALID, "node is null");
     for (Rank& k : nd->ranks) {

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(KickDriftArgs a) {
         const double F = -(gm * acc);
         double v = a.v64[(size_t)k * a.pad + l];
         double x = a.x64[(size_t)k * a.pad + l];
-        v += (F / m) * a.dt;
-        x += v * a.dt;
+        v += (F / m) * a.dt_kick;
+        x += v * a.dt_drift;
         a.v64[(size_t)k * a.pad + l] = v;
         a.x64[(size_t)k * a.pad + l] = x;
         a.pos_chunk[(size_t)k * a.pad + l] = (float)x;

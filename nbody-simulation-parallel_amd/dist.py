@@ -104,6 +104,9 @@ class HipShardBackend:
     def kick_drift(self, G: float, dt: float):
         self.ctx.kick_drift(dt, G)
 
+    def kick_drift2(self, G: float, dt_kick: float, dt_drift: float):
+        self.ctx.kick_drift2(dt_kick, dt_drift, G)
+
     def start_exchange(self, group):
         """Launch the position all-gather on the comm stream, ordered after everything already
         queued on the compute stream (the previous drift), and return the work handle."""
@@ -256,6 +259,17 @@ class ShardedNBody:
         for _ in range(nsteps):
             self.compute_forces()
             self.be.kick_drift(G, dt)
+
+    def step_kdk(self, dt: float, G: float = capi.REFERENCE_G, nsteps: int = 1):
+        """Extension: synchronised kick-drift-kick leapfrog (second order), adjacent half-kicks merged:
+        K(dt/2) D(dt) [F K(dt) D(dt)]^(n-1) F K(dt/2) -- n + 1 force evaluations (each with its exchange) for n steps."""
+        if nsteps <= 0:
+            return
+        self.compute_forces()
+        for s in range(nsteps):
+            self.be.kick_drift2(G, 0.5 * dt if s == 0 else dt, dt)
+            self.compute_forces()
+        self.be.kick_drift2(G, 0.5 * dt, 0.0)
 
     def forces(self, G: float = capi.REFERENCE_G) -> np.ndarray:
         return self.be.forces(G)

@@ -39,6 +39,7 @@ struct Options {
     std::string dump;               // prefix: write bodies and each method's forces as raw doubles
     double G = ::G;                 // --G: coupling constant of the HIP stepping loop (default: the reference's)
     int energy_every = 0;           // --energy-every k: log E and |dE/E0| every k steps of the loop
+    std::string integrator = "kd";  // --integrator kd|kdk: kick-drift as the reference helpers are ordered, or kick-drift-kick (extension)
     std::string law = "reference";  // --law reference|newton: pair law of the stepping loop (newton: extension, needs --softening)
     double softening = 0.0;         // --softening eps: Plummer-softened law in the stepping loop (extension; 0 = reference law)
     std::vector<int> devices;       // --gpus / --devices: shard the HIP rows over these GPUs (one process)
@@ -218,6 +219,7 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
         out << "Leapfrog (kick-drift) on HIP: " << opt.steps << " steps, dt = " << opt.dt << ", G = " << opt.G;
         if (opt.softening > 0.0) out << ", softening = " << opt.softening;
         if (opt.law != "reference") out << ", law = " << opt.law;
+        if (opt.integrator != "kd") out << ", integrator = " << opt.integrator;
         out << std::endl;
         std::vector<Body<D>> state = bodies;
         double kernel_s = 0.0;
@@ -232,7 +234,7 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
             }
             for (int done = 0; done < opt.steps;) {
                 const int k = std::min(chunk, opt.steps - done);
-                sim.step(opt.dt, k);
+                if (opt.integrator == "kdk") sim.step_kdk(opt.dt, k); else sim.step(opt.dt, k);
                 done += k;
                 if (opt.energy_every > 0) {
                     sim.energy(ke, pe);
@@ -276,6 +278,8 @@ void usage(const char* argv0) {
               << "      --steps <k>     Also run k kick-drift steps on the device" << std::endl
               << "      --dt <t>        Time step for --steps (default: 1)" << std::endl
               << "      --G <value>     Coupling constant of the stepping loop (default: the reference's 4.471e-21)" << std::endl
+              << "      --integrator <kd|kdk> kd = update_body_velocities then update_body_positions per step (default, first order);" << std::endl
+              << "                      kdk = the same helpers as a synchronised kick-drift-kick leapfrog (extension, second order)" << std::endl
               << "      --law <reference|newton> Pair law of the stepping loop: the reference's r^-4 form (default) or the attractive" << std::endl
               << "                      softened Newtonian law (extension; needs --softening; Plummer velocities then use --G)" << std::endl
               << "      --softening <eps> Plummer softening of the stepping loop's pair law (extension; default 0 = the reference's law)" << std::endl
@@ -329,6 +333,12 @@ int main(int argc, char* argv[]) {
             opt.energy_every = std::stoi(argv[++i]);
         } else if (arg == "--softening" && has_value) {
             opt.softening = std::stod(argv[++i]);
+        } else if (arg == "--integrator" && has_value) {
+            opt.integrator = argv[++i];
+            if (opt.integrator != "kd" && opt.integrator != "kdk") {
+                std::cerr << "Error: --integrator must be kd or kdk" << std::endl;
+                return 1;
+            }
         } else if (arg == "--law" && has_value) {
             opt.law = argv[++i];
             if (opt.law != "reference" && opt.law != "newton") {

@@ -130,6 +130,11 @@ void HipSimulation<D>::step(double dt, int nsteps) {
     if (rc != NBX_OK) raise("HipSimulation::step", rc);
 }
 template <int D>
+void HipSimulation<D>::step_kdk(double dt, int nsteps) {
+    const int rc = nbx_node_step_kdk(node_, G_, dt, nsteps);
+    if (rc != NBX_OK) raise("HipSimulation::step_kdk", rc);
+}
+template <int D>
 void HipSimulation<D>::energy(double& kinetic, double& potential) {
     const int rc = nbx_node_energy(node_, G_, &kinetic, &potential);
     if (rc != NBX_OK) raise("HipSimulation::energy", rc);

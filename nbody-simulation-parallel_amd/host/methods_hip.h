@@ -42,7 +42,8 @@ public:
     ~HipSimulation();
     HipSimulation(const HipSimulation&) = delete;
     HipSimulation& operator=(const HipSimulation&) = delete;
-    void step(double dt, int nsteps);            // asynchronous
+    void step(double dt, int nsteps);            // asynchronous; the reference helpers' order: kick, then drift
+    void step_kdk(double dt, int nsteps);        // extension: synchronised kick-drift-kick leapfrog (second order)
     void energy(double& kinetic, double& potential);  // of the whole system, under the reference law's potential
     void download(std::vector<Body<D>>& bodies);
     double force_kernel_seconds();               // per-rank force-kernel time since the last call

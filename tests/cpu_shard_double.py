@@ -52,6 +52,13 @@ class CpuShardDouble:
         self.x += self.v * dt
         self.pos_all[self.layout.shard, :, : self.layout.count] = torch.from_numpy(self.x.T.astype(np.float32))
 
+    def kick_drift2(self, G, dt_kick, dt_drift):
+        self.calls.append("kick_drift2")
+        F = -((G * self.m)[:, None] * self.acc)
+        self.v += (F / self.m[:, None]) * dt_kick
+        self.x += self.v * dt_drift
+        self.pos_all[self.layout.shard, :, : self.layout.count] = torch.from_numpy(self.x.T.astype(np.float32))
+
     def start_exchange(self, group):
         self.calls.append("exchange")
         if self.layout.n_shards == 1:

@@ -52,9 +52,14 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         final = sysm.gather_bodies(bodies)
         ncalls = len(be.calls)
         ke, pe = sysm.energy(o.G * gscale)
+        # kick-drift-kick form from the same state, on a copy of the back end's state
+        be2 = CpuShardDouble(bodies, layout)
+        sys2 = pkg.dist.ShardedNBody(be2, layout)
+        sys2.step_kdk(dt, o.G * gscale, steps)
+        final_kdk = sys2.gather_bodies(bodies)
         lo, hi = layout.bounds()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi, calls=np.array(be.calls[:ncalls]),
-                 energy=np.array([ke, pe]), verify=np.array([clean, broken]))
+                 energy=np.array([ke, pe]), verify=np.array([clean, broken]), final_kdk=final_kdk)
     finally:
         dist.destroy_process_group()
 
@@ -96,6 +101,19 @@ def test_sharded_steps_match_oracle(tmp_path, oracle, world, n, dim):
         for r in range(world):
             e = np.load(os.path.join(tmp_path, f"rank{r}.npz"))["energy"]
             assert abs(e[0] - ke_ref) <= 1e-12 * abs(ke_ref) and abs(e[1] - pe_ref * gscale) <= 1e-9 * abs(pe_ref * gscale)
+    # kick-drift-kick: the oracle's helpers composed the same way (half kick, drift, force, half kick)
+    kref = bodies.copy()
+    for _ in range(steps):
+        f = oracle.brute_force_seq(oracle.round_inputs_to_f32(kref)) * gscale
+        oracle.update_body_velocities(kref, np.ascontiguousarray(f), dt / 2)
+        oracle.update_body_positions(kref, dt)
+        f = oracle.brute_force_seq(oracle.round_inputs_to_f32(kref)) * gscale
+        oracle.update_body_velocities(kref, np.ascontiguousarray(f), dt / 2)
+    kd = np.load(os.path.join(tmp_path, "rank0.npz"))["final_kdk"]
+    if n > 1:
+        dvk = np.abs(kref[:, dim:2 * dim] - bodies[:, dim:2 * dim]).max()
+        assert np.allclose(kd[:, dim:2 * dim], kref[:, dim:2 * dim], rtol=0, atol=1e-7 * dvk)   # merged half-kicks: (a+b)*dt vs a*dt/2+b*dt/2
+    assert np.allclose(kd[:, :dim], kref[:, :dim], rtol=1e-12, atol=0)
     d = dim
     if n > 1:
         moved = np.abs(ref[:, d:2 * d] - bodies[:, d:2 * d]).max()
