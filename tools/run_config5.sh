@@ -19,10 +19,11 @@ EVERY="${EVERY:-50}"
 G="${G:-0.05}"
 SOFTENING="${SOFTENING:-0}"
 LAW="${LAW:-reference}"
+INTEGRATOR="${INTEGRATOR:-kd}"       # kd = the reference helpers' order (kick, drift); kdk = synchronised leapfrog (extension)
 OUT="${OUT:-gpurun_out/config5_${GPUS}gpu_${STEPS}steps.log}"
 mkdir -p "$(dirname "$OUT")"
 [ -x ./nbody_sim ] || make nbody_sim
 if [ -n "$DEVICES" ]; then where=(--devices "$DEVICES"); else where=(--gpus "$GPUS"); fi
-./nbody_sim -N "$N" -d 3 -m g --init plummer --seed 5 --G "$G" --law "$LAW" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" "${where[@]}" | tee "$OUT"
+./nbody_sim -N "$N" -d 3 -m g --init plummer --seed 5 --G "$G" --law "$LAW" --integrator "$INTEGRATOR" --softening "$SOFTENING" --dt 0.5 --steps "$STEPS" --energy-every "$EVERY" "${where[@]}" | tee "$OUT"
 grep -E "^step |Time taken|Kernel time" "$OUT" > "${OUT%.log}.summary.txt"
 echo "summary: ${OUT%.log}.summary.txt"
