@@ -298,8 +298,10 @@ def main():
         # HBM traffic of the force kernel per launch: PMC counters cannot be read from inside the process; they come from
         # the committed rocprofv3 --pmc passes of this same command (tools/profile_bench.sh -> tools/summarize_prof.py ->
         # profiles/<round>/pmc_force_kernel.json), and only if that profile is of the kernel that just ran -- otherwise the
-        # field stays null and says why.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads (guide: the x2 correction
-        # applies to 16-byte streaming loads), so the raw sum is reported.
+        # field stays null and says why.  Units and gfx950 corrections as the guide's HBM section prescribes: KB -> bytes;
+        # FETCH_SIZE under-reports coalesced streaming reads by 2 on gfx950 -- confirmed for THIS path's 4-/8-byte-per-lane
+        # streams by the helper kernels of the same profile, whose byte counts are known exactly (classify_*: 12 B/body,
+        # kick_drift: (12 S + 56) B/body read, 60 B/body written: "calibration" in the json, true/reported = 2.00 and 1.00).
         kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1>",
                      "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>"}
         prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
@@ -310,9 +312,16 @@ def main():
             if kernel_of.get(variant_name, "?") in profiled and profiled == pmc["pmc_write"]["kernel"]["Kernel_Name"]:
                 fetch_kb = pmc["pmc_fetch"]["per_launch_mean"]["FETCH_SIZE"]
                 write_kb = pmc["pmc_write"]["per_launch_mean"]["WRITE_SIZE"]
-                result["roofline"]["traffic"] = (fetch_kb + write_kb) * 1024.0
-                result["roofline"]["traffic_source"] = (f"{prof}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command and this kernel "
-                                                        f"({fetch_kb / 1024:.0f} + {write_kb / 1024:.0f} MiB per launch, raw)")
+                cal = pmc.get("calibration", {})
+                ff = [v["FETCH_SIZE"]["true_over_reported"] for v in cal.values() if "FETCH_SIZE" in v]
+                wf = [v["WRITE_SIZE"]["true_over_reported"] for v in cal.values() if "WRITE_SIZE" in v]
+                f_fetch = sum(ff) / len(ff) if ff else 2.0      # guide: x2 on gfx950 for coalesced streaming reads
+                f_write = sum(wf) / len(wf) if wf else 1.0
+                result["roofline"]["traffic"] = (f_fetch * fetch_kb + f_write * write_kb) * 1024.0
+                result["roofline"]["traffic_source"] = (f"{prof}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) of this command and this "
+                                                        f"kernel, per launch: {fetch_kb / 1024:.0f} MiB x {f_fetch:.2f} fetched + {write_kb / 1024:.0f} MiB "
+                                                        f"x {f_write:.2f} written; factors calibrated on the helper kernels of the same profile "
+                                                        "(known byte counts), = the guide's gfx950 FETCH_SIZE correction")
             else:
                 result["roofline"]["traffic_source"] = f"stale: {prof} is a profile of '{profiled}', the run used variant {variant_name}"
         except Exception as e:

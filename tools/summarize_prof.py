@@ -52,6 +52,37 @@ def main():
                 counts[k] += 1
         if meta:
             out[sub] = {"kernel": meta, "per_launch_mean": {k: sums[k] / counts[k] for k in sums}, "launches": dict(counts)}
+    # Calibration of FETCH_SIZE / WRITE_SIZE in THIS path's access pattern (guide: "calibrate on a known byte count in your own
+    # access pattern"): the helper kernels of the same run read and write exactly known byte counts with the same coalesced
+    # 4-/8-byte-per-lane streams -- classify_*_kernel reads 12 B per body, kick_drift_kernel reads (12 S + 56) B and writes
+    # 60 B per body (S = source slices).
+    cfg = {}
+    try:
+        cfg = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())["config"]
+    except Exception:
+        pass
+    n, S = cfg.get("n_bodies"), cfg.get("source_slices")
+    if n and S:
+        known = {"classify_close_kernel": (12.0 * n, None), "classify_sources_kernel": (12.0 * n, None),
+                 "kick_drift_kernel": ((12.0 * S + 56.0) * n, 60.0 * n)}
+        calib = {}
+        for sub, counter, col in (("pmc_fetch", "FETCH_SIZE", 0), ("pmc_write", "WRITE_SIZE", 1)):
+            path = os.path.join(src, sub, "bench_counter_collection.csv")
+            if not os.path.exists(path):
+                continue
+            per = defaultdict(lambda: defaultdict(float))
+            for r in csv.DictReader(open(path)):
+                for k in known:
+                    if k in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        per[k][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for k, d in per.items():
+                true_bytes = known[k][col]
+                if true_bytes and d:
+                    mean_kb = sum(d.values()) / len(d)
+                    calib.setdefault(k, {})[counter] = {"reported_KB": mean_kb, "true_KB": true_bytes / 1024.0,
+                                                        "true_over_reported": true_bytes / 1024.0 / mean_kb, "launches": len(d)}
+        if calib:
+            out["calibration"] = calib
     if out:
         with open(os.path.join(dst, "pmc_force_kernel.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
