@@ -247,7 +247,23 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
 }
 
 template <int D>
-__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile]);
+__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile], unsigned bx, unsigned by);
+
+// XCD-aware workgroup -> (target block, source slice) mapping.  The 256 CUs are 8 XCDs with a private 4 MiB L2 each, and
+// the hardware deals consecutive workgroups (x fastest, then y) round-robin over the XCDs.  With the natural mapping and a
+// grid width that is a multiple of 8, XCD k gets the target blocks x = k mod 8 and ALL source slices: every L2 streams the
+// whole source set, which does not fit it (0.4-0.5 GB of fabric reads per launch at N = 2^20 against 29 MB algorithmic).
+// Here XCD k owns source slices [k S/8, (k+1) S/8) for ALL target blocks: its share of the sources (2 MiB at N = 2^20) stays
+// resident in its L2 and is fetched once.  Placement is a speed matter only -- any mapping is correct.
+constexpr unsigned kXcds = 8;
+__device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
+    const unsigned S = gridDim.y;
+    if (S % kXcds != 0) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;   // dispatch order; workgroup L runs on XCD L % 8
+    const unsigned xcd = L % kXcds, idx = L / kXcds, per = S / kXcds;
+    by = xcd * per + idx % per;
+    bx = idx / per;
+}
 
 // -------------------------------------------------------------------------------------------------
 // Fast packed LDS kernel: PAIRS float2 target pairs per lane (TPL = 2*PAIRS), no per-pair guard
@@ -260,17 +276,19 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // and there is no close set: close_blocks = 0, bad_flag is not read.
 // SOFT = 2: softened NEWTONIAN law  a_i = sum_j m_j d / (r^2 + eps^2)^(3/2)  (nbx_ctx_set_law; the `--law newton` of
 // SURVEY 5/7; attractive -- the sign is applied with G by the consumers).  Never combined with ONE_RCP.
-template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0, int HI_SEL = 1>
+template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0, int HI_SEL = 1, int XCD_MAP = 1>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
-    if (!SOFT && blockIdx.x < a.close_blocks) {  // the launch's extra workgroups: guarded evaluation of the close set
-        close_set_path<D>(a, tile);
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx, by);
+    if (!SOFT && bx < a.close_blocks) {  // the launch's extra workgroups: guarded evaluation of the close set
+        close_set_path<D>(a, tile, bx, by);
         return;
     }
     const f2 bias = SOFT ? f2{a.eps2, a.eps2} : f2{kTiny, kTiny};
     const unsigned tid = threadIdx.x;
-    const unsigned tgt0 = (blockIdx.x - a.close_blocks) * (256u * TPL) + tid;
+    const unsigned tgt0 = (bx - a.close_blocks) * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], ox[PAIRS], oy[PAIRS], oz[PAIRS];
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
         ox[q] = oy[q] = oz[q] = f2{0.f, 0.f};
     }
 
-    unsigned t = blockIdx.y * a.tiles_per_split;
+    unsigned t = by * a.tiles_per_split;
     unsigned t_end = t + a.tiles_per_split;
     if (t_end > a.total_tiles) t_end = a.total_tiles;
     TileWalk w;
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
         buf ^= 1;
     }
 
-    float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
+    float* __restrict__ out = a.acc + (size_t)by * D * a.pad;
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
 #pragma unroll
@@ -415,11 +433,11 @@ __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
 }
 
 template <int D>
-__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile]) {
+__device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile], const unsigned bx, const unsigned by) {
     const unsigned tid = threadIdx.x;
     const unsigned n = a.counters[1];
     const unsigned nblk = (n + 255u) / 256u;
-    const unsigned cx = blockIdx.x, cstride = a.close_blocks;
+    const unsigned cx = bx, cstride = a.close_blocks;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     for (unsigned tb = cx; tb < nblk; tb += cstride) {
@@ -429,7 +447,7 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
         const float ix = tp[i], iy = tp[(size_t)a.pad + i], iz = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
         double ox = 0.0, oy = 0.0, oz = 0.0;
 
-        unsigned t = blockIdx.y * a.tiles_per_split;
+        unsigned t = by * a.tiles_per_split;
         unsigned t_end = t + a.tiles_per_split;
         if (t_end > a.total_tiles) t_end = a.total_tiles;
         TileWalk w;
@@ -455,7 +473,7 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
             buf ^= 1;
         }
         if (valid) {
-            float* __restrict__ o = a.close_acc + (size_t)blockIdx.y * D * a.pad;
+            float* __restrict__ o = a.close_acc + (size_t)by * D * a.pad;
             o[slot] = (float)ox;
             o[(size_t)a.pad + slot] = (float)oy;
             if (D == 3) o[2 * (size_t)a.pad + slot] = (float)oz;
@@ -581,6 +599,7 @@ const KernelVariant kVariants[] = {
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
     {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
+    {"fastpk_t8_w3_u4_noxcd", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 1, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
 #endif
     {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
 };
