@@ -96,29 +96,52 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
     const uint32_t slot = tb.first + (valid ? tid : 0u);
     const float ix = a.x[slot], iy = a.x[(size_t)a.slots + slot], iz = (D == 3) ? a.x[2 * (size_t)a.slots + slot] : 0.0f;
     double ox = 0.0, oy = 0.0, oz = 0.0;
-    const uint32_t e0 = a.list_offsets[tb.leaf], e1 = a.list_offsets[tb.leaf + 1];
-    for (uint32_t e = e0; e < e1; ++e) {                       // wave-uniform walk of the leaf's source list
-        const uint32_t s = a.list_sources[e];
-        const uint32_t b0 = a.leaf_offsets[s], b1 = a.leaf_offsets[s + 1];
-        for (uint32_t base = b0; base < b1; base += BLOCK) {
-            const uint32_t cnt = (b1 - base < (uint32_t)BLOCK) ? b1 - base : (uint32_t)BLOCK;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < cnt) {
-                const uint32_t j = base + tid;
-                v.x = a.x[j];
-                v.y = a.x[(size_t)a.slots + j];
-                v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
-                v.w = a.m[j];
-            }
-            __syncthreads();                                   // previous tile fully consumed
-            tile[tid] = v;
-            __syncthreads();
-            float ax = 0.f, ay = 0.f, az = 0.f;
-            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
-            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-            for (uint32_t j = 0; j < cnt; ++j) leaf_interact<D, LAW>(tile[j], ix, iy, iz, ax, ay, az);
-            ox += (double)ax; oy += (double)ay; oz += (double)az;
+    // Walk the leaf's source list as one stream of tiles (<= BLOCK bodies of one source leaf each), software-pipelined: the
+    // next tile's global loads are issued before the current tile is consumed, so their latency hides behind the pair loop
+    // (leaves are small: without this every tile paid a full L2 round trip in front of ~30 sources of arithmetic).
+    // All of it is workgroup-uniform control flow.
+    uint32_t e = a.list_offsets[tb.leaf];
+    const uint32_t e1 = a.list_offsets[tb.leaf + 1];
+    uint32_t base = 0, end = 0;
+    auto advance = [&]() -> bool {             // move to the next non-empty tile of the stream
+        base += BLOCK;
+        while (base >= end) {
+            if (e >= e1) return false;
+            const uint32_t s = a.list_sources[e++];
+            base = a.leaf_offsets[s];
+            end = a.leaf_offsets[s + 1];
         }
+        return true;
+    };
+    auto load = [&](uint32_t cnt) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < cnt) {
+            const uint32_t j = base + tid;
+            v.x = a.x[j];
+            v.y = a.x[(size_t)a.slots + j];
+            v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
+            v.w = a.m[j];
+        }
+        return v;
+    };
+    bool has = advance();
+    uint32_t cnt = has ? ((end - base < (uint32_t)BLOCK) ? end - base : (uint32_t)BLOCK) : 0u;
+    float4 nxt = has ? load(cnt) : make_float4(0.f, 0.f, 0.f, 0.f);
+    while (has) {
+        const uint32_t cur = cnt;
+        __syncthreads();                                       // previous tile fully consumed
+        tile[tid] = nxt;
+        __syncthreads();
+        has = advance();
+        if (has) {
+            cnt = (end - base < (uint32_t)BLOCK) ? end - base : (uint32_t)BLOCK;
+            nxt = load(cnt);                                   // in flight while this tile is consumed
+        }
+        // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
+        // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        for (uint32_t j = 0; j < cur; ++j) leaf_interact<D, LAW>(tile[j], ix, iy, iz, ax, ay, az);
+        ox += (double)ax; oy += (double)ay; oz += (double)az;
     }
     if (valid) {
         a.acc[slot] = ox;
