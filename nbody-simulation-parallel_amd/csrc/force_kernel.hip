@@ -599,6 +599,11 @@ const KernelVariant kVariants[] = {
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
     {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
+    {"fastpk_t8_w3_u2", 8, NBX_FAST(4, 3, 2, 0)},
+    {"fastpk_t8_w3_u8", 8, NBX_FAST(4, 3, 8, 0)},
+    {"fastpk_t8_w2_u4", 8, NBX_FAST(4, 2, 4, 0)},
+    {"fastpk_t4_w6_u4", 4, NBX_FAST(2, 6, 4, 0)},
+    {"fastpk_t16_w1_u2", 16, NBX_FAST(8, 1, 2, 0)},
     {"fastpk_t8_w3_u4_noxcd", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 1, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
 #endif
     {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
