@@ -187,6 +187,22 @@ __device__ __forceinline__ void store_result(const KArgs& a, float* __restrict__
     }
 }
 
+// XCD-aware workgroup -> (target block, source slice) mapping.  The 256 CUs are 8 XCDs with a private 4 MiB L2 each, and
+// the hardware deals consecutive workgroups (x fastest, then y) round-robin over the XCDs.  With the natural mapping and a
+// grid width that is a multiple of 8, XCD k gets the target blocks x = k mod 8 and ALL source slices: every L2 streams the
+// whole source set, which does not fit it (0.4-0.5 GB of fabric reads per launch at N = 2^20 against 29 MB algorithmic).
+// Here XCD k owns source slices [k S/8, (k+1) S/8) for ALL target blocks: its share of the sources (2 MiB at N = 2^20) stays
+// resident in its L2 and is fetched once.  Placement is a speed matter only -- any mapping is correct.
+constexpr unsigned kXcds = 8;
+__device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
+    const unsigned S = gridDim.y;
+    if (S % kXcds != 0) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;   // dispatch order; workgroup L runs on XCD L % 8
+    const unsigned xcd = L % kXcds, idx = L / kXcds, per = S / kXcds;
+    by = xcd * per + idx % per;
+    bx = idx / per;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Exact LDS kernel: 256 lanes, TPL targets per lane, compare-and-select guard on every pair,
 // fp64 second-level accumulators.  Self-contained (no close-set pipeline).
@@ -195,7 +211,9 @@ template <int D, int TPL, int WAVES, int UNROLL>
 __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     __shared__ float4 tile[2][kTile];
     const unsigned tid = threadIdx.x;
-    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    const unsigned tgt0 = bx * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     float ix[TPL], iy[TPL], iz[TPL];
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
         ox[q] = oy[q] = oz[q] = 0.0;
     }
 
-    unsigned t = blockIdx.y * a.tiles_per_split;
+    unsigned t = by * a.tiles_per_split;
     unsigned t_end = t + a.tiles_per_split;
     if (t_end > a.total_tiles) t_end = a.total_tiles;
     TileWalk w;
@@ -241,29 +259,13 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
         buf ^= 1;
     }
 
-    float* __restrict__ out = a.acc + (size_t)blockIdx.y * D * a.pad;
+    float* __restrict__ out = a.acc + (size_t)by * D * a.pad;
 #pragma unroll
     for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
 }
 
 template <int D>
 __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile], unsigned bx, unsigned by);
-
-// XCD-aware workgroup -> (target block, source slice) mapping.  The 256 CUs are 8 XCDs with a private 4 MiB L2 each, and
-// the hardware deals consecutive workgroups (x fastest, then y) round-robin over the XCDs.  With the natural mapping and a
-// grid width that is a multiple of 8, XCD k gets the target blocks x = k mod 8 and ALL source slices: every L2 streams the
-// whole source set, which does not fit it (0.4-0.5 GB of fabric reads per launch at N = 2^20 against 29 MB algorithmic).
-// Here XCD k owns source slices [k S/8, (k+1) S/8) for ALL target blocks: its share of the sources (2 MiB at N = 2^20) stays
-// resident in its L2 and is fetched once.  Placement is a speed matter only -- any mapping is correct.
-constexpr unsigned kXcds = 8;
-__device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
-    const unsigned S = gridDim.y;
-    if (S % kXcds != 0) { bx = blockIdx.x; by = blockIdx.y; return; }
-    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;   // dispatch order; workgroup L runs on XCD L % 8
-    const unsigned xcd = L % kXcds, idx = L / kXcds, per = S / kXcds;
-    by = xcd * per + idx % per;
-    bx = idx / per;
-}
 
 // -------------------------------------------------------------------------------------------------
 // Fast packed LDS kernel: PAIRS float2 target pairs per lane (TPL = 2*PAIRS), no per-pair guard
@@ -516,7 +518,9 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     constexpr int TPL = 2;
     __shared__ float4 tile[2][kTile];
     const unsigned tid = threadIdx.x;
-    const unsigned tgt0 = blockIdx.x * (256u * TPL) + tid;
+    unsigned bx, by;
+    xcd_tile(bx, by);
+    const unsigned tgt0 = bx * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
     float ix[TPL], iy[TPL], iz[TPL];
     double o[TPL];
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
         iz[q] = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
         o[q] = 0.0;
     }
-    unsigned t = blockIdx.y * a.tiles_per_split;
+    unsigned t = by * a.tiles_per_split;
     unsigned t_end = t + a.tiles_per_split;
     if (t_end > a.total_tiles) t_end = a.total_tiles;
     TileWalk w;
@@ -540,8 +544,8 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
         tile[buf][tid] = nxt;
         __syncthreads();
         // softened law: a body's own entry (r^2 = 0, weight m/eps^2) is excluded by INDEX -- the tile that holds this
-        // workgroup's q-th targets is tile (blockIdx.x*TPL + q) of the target chunk, entry tid (workgroup-uniform test)
-        const unsigned rel = w.k - blockIdx.x * TPL;
+        // workgroup's q-th targets is tile (bx*TPL + q) of the target chunk, entry tid (workgroup-uniform test)
+        const unsigned rel = w.k - bx * TPL;
         const bool own_tile = SOFT && w.chunk(a.chunk_first, a.chunk_skip) == a.tgt_chunk && rel < (unsigned)TPL;
         if (t + 1 < t_end) {
             w.next(a.tiles_per_chunk);
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
         for (int q = 0; q < TPL; ++q) o[q] += (double)p[q];
         buf ^= 1;
     }
-    float* __restrict__ out = a.acc + (size_t)blockIdx.y * a.pad;  // a.acc = phi[slice][pad] here
+    float* __restrict__ out = a.acc + (size_t)by * a.pad;  // a.acc = phi[slice][pad] here
 #pragma unroll
     for (int q = 0; q < TPL; ++q) out[tgt0 + q * 256u] = (float)o[q];
 }

@@ -123,6 +123,11 @@ def test_newtonian_law_matches_the_checker(nbx, oracle, dim):
         ke_ref, pe_ref = oracle.energy_softened(b, eps, newton=True)
         ke, pe = c.energy(oracle.G)
         assert pe < 0 and abs(pe - pe_ref) <= 2e-6 * abs(pe_ref) and abs(ke - ke_ref) <= 1e-13 * ke_ref
+        # the device-side accuracy metric follows the law's sign as well (scaled so that the 1 % rule bites)
+        scale = 1e12
+        good = c.accuracy(np.ascontiguousarray(ref * scale), oracle.G * scale)     # per-COMPONENT 1 % rule: a few cancelling
+        assert good >= 99.9 and good == oracle.compute_accuracy(np.ascontiguousarray(f * scale), np.ascontiguousarray(ref * scale))
+        assert c.accuracy(np.ascontiguousarray(-ref * scale), oracle.G * scale) < 5.0  # components miss it in fp32
         c.set_law(nbx.FORCE_LAW_REFERENCE)
         c.compute_accel()
         assert_force_parity(c.forces(oracle.G), rep, oracle.force_rows_softened(b, eps)[1], "back to the reference law, softened")
