@@ -33,18 +33,17 @@
 namespace nbx {
 namespace {
 
-enum Guard { GUARD_EXACT = 0, GUARD_TINY = 2 };  // GUARD_TINY: scalar form of the fast kernels' arithmetic (unused by the table)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // One pair interaction.  s{xyz,m} is wave-uniform (LDS broadcast or SGPR), i{xyz} per lane.
-template <int D, int GUARD>
+template <int D>
 __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
                                          float ix, float iy, float iz,
                                          float& ax, float& ay, float& az) {
     const float dx = sx - ix;
     const float dy = sy - iy;
-    float r2 = (GUARD == GUARD_TINY) ? __builtin_fmaf(dx, dx, kTiny) : dx * dx;
+    float r2 = dx * dx;
     r2 = __builtin_fmaf(dy, dy, r2);
     float dz = 0.0f;
     if (D == 3) {
@@ -52,7 +51,7 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
         r2 = __builtin_fmaf(dz, dz, r2);
     }
     // methods.cpp:24 -- `if (dist_sq < 1e-10) continue;`  rcp(+inf) = +0 makes the pair's weight 0.
-    const float r2g = (GUARD == GUARD_EXACT) ? ((r2 < kR2SkipF) ? __builtin_inff() : r2) : r2;
+    const float r2g = (r2 < kR2SkipF) ? __builtin_inff() : r2;
     const float ri2 = __builtin_amdgcn_rcpf(r2g);  // v_rcp_f32, 1 ulp
     const float t = sm * ri2;
     const float s = t * ri2;  // m_j / r^4
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
             const float4 s = cur[j];  // same address in every lane: ds_read_b128 broadcast
 #pragma unroll
             for (int q = 0; q < TPL; ++q)
-                interact<D, GUARD_EXACT>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
+                interact<D>(s.x, s.y, s.z, s.w, ix[q], iy[q], iz[q], ax[q], ay[q], az[q]);
         }
 #pragma unroll
         for (int q = 0; q < TPL; ++q) { ox[q] += (double)ax[q]; oy[q] += (double)ay[q]; oz[q] += (double)az[q]; }
@@ -469,7 +468,7 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 #pragma unroll 8
             for (int j = 0; j < kTile; ++j) {
                 const float4 s = cur[j];
-                interact<D, GUARD_EXACT>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
+                interact<D>(s.x, s.y, s.z, s.w, ix, iy, iz, ax, ay, az);
             }
             ox += (double)ax; oy += (double)ay; oz += (double)az;
             buf ^= 1;
