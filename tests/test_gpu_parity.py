@@ -556,7 +556,8 @@ def test_fuzz_fast_path_against_guarded_kernel(nbx, oracle):
     rng = np.random.default_rng(2026)
     exact = [i for i, v in enumerate(nbx.variants()) if "exact" in v][0]
     modes = set()
-    for case in range(36):
+    import os
+    for case in range(int(os.environ.get("NBX_FUZZ_CASES", "36"))):   # NBX_FUZZ_CASES=400 for a long soak
         dim = 3 if case % 3 else 2
         n = int(rng.integers(1500, 6000))
         scale = 10.0 ** rng.uniform(-2, 7)
