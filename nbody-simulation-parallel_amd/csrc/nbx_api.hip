@@ -108,6 +108,10 @@ int ensure_acc(nbx_ctx* c) {
         const int need = (int)((tiles + (unsigned)cap - 1) / (unsigned)cap);
         if (c->splits < need) c->splits = need;
     }
+    // Partial sums cost 12 B x slices x pad, and the slice count grows with the source count (<= 256 tiles per slice): a
+    // single shard of more than ~16 M bodies would ask for > 50 GB here.  Say so instead of failing in hipMalloc.
+    if ((size_t)c->splits * c->dim * c->pad * sizeof(float) > ((size_t)48 << 30))
+        return fail(NBX_ERR_ALLOC, "shard too large for the per-slice partial sums (12 B x slices x bodies > 48 GiB): split the bodies over more shards");
     if (!(c->acc && c->acc_splits_alloc >= c->splits)) {
         if (c->acc) { HIP_TRY(hipFree(c->acc)); c->acc = nullptr; }
         HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
