@@ -358,6 +358,7 @@ template <int D>
 __global__ __launch_bounds__(256) void classify_close_kernel(KArgs a) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.count) return;
+    a.bad_flag[i] = 0u;   // this launch's refinement starts from clean flags (entries >= count are never set)
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
     const float x = tp[i], y = tp[(size_t)a.pad + i], z = (D == 3) ? tp[2 * (size_t)a.pad + i] : 0.0f;
     if (in_close_set<D>(x, y, z)) {

@@ -100,27 +100,30 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     const int di = dim - 2;
     if (V.fast && !soft) {
         // Candidate targets: a property of the own chunk's positions (rebuilt after every position update).
-        if (!(L.tgt_cand_valid && *L.tgt_cand_valid)) {
-            if ((e = hipMemsetAsync(L.counters, 0, sizeof(unsigned), stream)) != hipSuccess) return e;
+        // Bad targets: a property of the own chunk AND of the pass's source chunks, which for a sharded ALL /
+        // REMOTE pass are rewritten behind the library's back by the exchange -- rebuilt for every such launch.
+        const bool build_targets = !(L.tgt_cand_valid && *L.tgt_cand_valid);
+        const bool build_bad = build_targets || !(L.cacheable && L.bad_list_pass && *L.bad_list_pass == L.pass);
+        if (build_targets) {   // one memset for all three counters; classify_close_kernel clears its targets' flags itself
+            if ((e = hipMemsetAsync(L.counters, 0, 3 * sizeof(unsigned), stream)) != hipSuccess) return e;
             if (L.count) {
                 hipLaunchKernelGGL(table().ck.classify[di], dim3((L.count + 255u) / 256u, 1, 1), block, 0, stream, a);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             }
             if (L.tgt_cand_valid) *L.tgt_cand_valid = 1;
             if (L.bad_list_pass) *L.bad_list_pass = -1;
-        }
-        // Bad targets: a property of the own chunk AND of the pass's source chunks, which for a sharded ALL /
-        // REMOTE pass are rewritten behind the library's back by the exchange -- rebuilt for every such launch.
-        if (!(L.cacheable && L.bad_list_pass && *L.bad_list_pass == L.pass)) {
+        } else if (build_bad) {
             if ((e = hipMemsetAsync(L.counters + 1, 0, 2 * sizeof(unsigned), stream)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(L.bad_flag, 0, (size_t)L.pad * sizeof(unsigned), stream)) != hipSuccess) return e;
+        }
+        if (build_bad) {
             if (L.count) {
                 hipLaunchKernelGGL(table().ck.classify_src[di], dim3(L.pad / 256u, (unsigned)L.vchunks, 1), block, 0, stream, a);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 if (L.hash.keys) {   // most bodies are candidates: sorted cells instead of candidates x candidates
                     if ((e = hash_refine(dim, a, L.hash, stream)) != hipSuccess) return e;
                 } else {
-                    hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
+                    hipLaunchKernelGGL(table().ck.refine[di], dim3(256, 1, 1), block, 0, stream, a);
                     if ((e = hipGetLastError()) != hipSuccess) return e;
                 }
             }

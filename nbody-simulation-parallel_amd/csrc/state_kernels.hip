@@ -42,22 +42,25 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs p) {
 
 // K3: fused kick + drift (methods.cpp:436 then :448), fp64:
 //   F = -(G m) a ;  v += (F / m) * dt ;  x += v * dt ;  pos32 = (float)x
+// One lane per (body, component): grid.y = component.  The components are independent (v_k += (F_k/m) dt; x_k += v_k dt),
+// so this is the same arithmetic in the same order as a loop over k in one lane -- with dim times the lanes in flight,
+// which is what a latency-bound kernel wants at small N (one lane per body was 25 us at N = 65,536: S = 32 dependent-address
+// loads per component and one workgroup per CU).
 __global__ __launch_bounds__(256) void kick_drift_kernel(KickDriftArgs a) {
     const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (l >= a.count) return;
+    const int k = (int)blockIdx.y;
     const double m = a.m64[l];
     const double gm = a.G * m;
-    for (int k = 0; k < a.dim; ++k) {
-        const double acc = sum_partials(a.acc, a.splits, a.dim, a.pad, k, l);
-        const double F = -(gm * acc);
-        double v = a.v64[(size_t)k * a.pad + l];
-        double x = a.x64[(size_t)k * a.pad + l];
-        v += (F / m) * a.dt_kick;
-        x += v * a.dt_drift;
-        a.v64[(size_t)k * a.pad + l] = v;
-        a.x64[(size_t)k * a.pad + l] = x;
-        a.pos_chunk[(size_t)k * a.pad + l] = (float)x;
-    }
+    const double acc = sum_partials(a.acc, a.splits, a.dim, a.pad, k, l);
+    const double F = -(gm * acc);
+    double v = a.v64[(size_t)k * a.pad + l];
+    double x = a.x64[(size_t)k * a.pad + l];
+    v += (F / m) * a.dt_kick;
+    x += v * a.dt_drift;
+    a.v64[(size_t)k * a.pad + l] = v;
+    a.x64[(size_t)k * a.pad + l] = x;
+    a.pos_chunk[(size_t)k * a.pad + l] = (float)x;
 }
 
 __global__ __launch_bounds__(256) void export_forces_kernel(const float* __restrict__ acc, int splits, int dim,
@@ -158,7 +161,7 @@ hipError_t launch_pack(const PackArgs& p, hipStream_t stream) {
 
 hipError_t launch_kick_drift(const KickDriftArgs& k, hipStream_t stream) {
     if (k.count == 0) return hipSuccess;
-    hipLaunchKernelGGL(kick_drift_kernel, dim3(blocks_for(k.count)), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL(kick_drift_kernel, dim3(blocks_for(k.count), (unsigned)k.dim, 1), dim3(256), 0, stream, k);
     return hipGetLastError();
 }
 
