@@ -397,11 +397,12 @@ __global__ __launch_bounds__(256) void classify_sources_kernel(KArgs a) {
 // long workgroups; a target found bad by several workgroups is listed once (atomicExch on its flag).
 template <int D>
 __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
-    __shared__ float tx[256], ty[256], tz[256];
+    constexpr unsigned kSrcBlock = 64;   // sources per work item: short items, many of them (a 256-source item ran 20 us alone on a CU)
+    __shared__ float tx[kSrcBlock], ty[kSrcBlock], tz[kSrcBlock];
     const unsigned tid = threadIdx.x;
     const unsigned n = a.counters[0];    // candidate targets (own chunk)
     const unsigned ns = a.counters[2];   // candidate sources (the pass's chunks)
-    const unsigned nblk = (n + 255u) / 256u, nsblk = (ns + 255u) / 256u;
+    const unsigned nblk = (n + 255u) / 256u, nsblk = (ns + kSrcBlock - 1u) / kSrcBlock;
     const bool keep_all = n > kRefineLimit || (unsigned long long)n * ns > kRefinePairLimit;
     const unsigned long long npairs = keep_all ? nblk : (unsigned long long)nblk * nsblk;
     for (unsigned long long p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -412,14 +413,16 @@ __global__ __launch_bounds__(256) void refine_close_kernel(KArgs a) {
         const float x = a.cand_pos[ls], y = a.cand_pos[(size_t)a.pad + ls], z = (D == 3) ? a.cand_pos[2 * (size_t)a.pad + ls] : 0.0f;
         bool bad = keep_all;
         if (!keep_all) {
-            const unsigned j = sb * 256u + tid;
+            const unsigned j = sb * kSrcBlock + tid;
             __syncthreads();
-            // out-of-range entries duplicate this lane's own position: r^2 = 0, never "bad"
-            tx[tid] = (j < ns) ? a.src_cand_pos[j] : x;
-            ty[tid] = (j < ns) ? a.src_cand_pos[(size_t)a.src_stride + j] : y;
-            tz[tid] = (D == 3 && j < ns) ? a.src_cand_pos[2 * (size_t)a.src_stride + j] : z;
+            if (tid < kSrcBlock) {
+                const bool in = j < ns;
+                tx[tid] = in ? a.src_cand_pos[j] : 0.0f;
+                ty[tid] = in ? a.src_cand_pos[(size_t)a.src_stride + j] : 0.0f;
+                tz[tid] = (D == 3 && in) ? a.src_cand_pos[2 * (size_t)a.src_stride + j] : 0.0f;
+            }
             __syncthreads();
-            const unsigned lim = (ns - sb * 256u < 256u) ? ns - sb * 256u : 256u;
+            const unsigned lim = (ns - sb * kSrcBlock < kSrcBlock) ? ns - sb * kSrcBlock : kSrcBlock;   // entries beyond lim are never read
             for (unsigned k = 0; k < lim; ++k) {
                 const float dx = tx[k] - x, dy = ty[k] - y;
                 float r2 = __builtin_fmaf(dy, dy, dx * dx);

@@ -123,7 +123,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
                 if (L.hash.keys) {   // most bodies are candidates: sorted cells instead of candidates x candidates
                     if ((e = hash_refine(dim, a, L.hash, stream)) != hipSuccess) return e;
                 } else {
-                    hipLaunchKernelGGL(table().ck.refine[di], dim3(256, 1, 1), block, 0, stream, a);
+                    hipLaunchKernelGGL(table().ck.refine[di], dim3(1024, 1, 1), block, 0, stream, a);
                     if ((e = hipGetLastError()) != hipSuccess) return e;
                 }
             }
