@@ -302,7 +302,7 @@ def main():
         # FETCH_SIZE under-reports coalesced streaming reads by 2 on gfx950 -- confirmed for THIS path's 4-/8-byte-per-lane
         # streams by the helper kernels of the same profile, whose byte counts are known exactly (classify_*: 12 B/body,
         # kick_drift: (12 S + 56) B/body read, 60 B/body written: "calibration" in the json, true/reported = 2.00 and 1.00).
-        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1>",
+        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1>",
                      "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>"}
         prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
         try:
