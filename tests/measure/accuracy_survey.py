@@ -11,6 +11,17 @@ import nbody_amd as nbx
 from oracle_lib import Oracle, force_errors
 
 o = Oracle()
+
+# the oracle calls below are single blocking C calls of several minutes at N = 2^20: keep a heartbeat on stderr so that a
+# supervised run is not taken for hung (ctypes releases the GIL during the call)
+import threading
+def _heartbeat():
+    t0 = time.time()
+    while True:
+        time.sleep(60)
+        sys.stderr.write(f"[accuracy_survey] still working, {time.time() - t0:.0f} s\n")
+        sys.stderr.flush()
+threading.Thread(target=_heartbeat, daemon=True).start()
 cases = [(65536, 3, None, 2), (65536, 2, None, 2), (1 << 20, 3, 2048, 3), (1 << 20, 2, 1024, 3)]
 if "full20" in sys.argv[1:]:        # every one of the 1,048,576 bodies against the oracle: ~5 minutes of host time at 16 threads
     cases = [(1 << 20, 3, None, 3)]
