@@ -184,12 +184,15 @@ LeafKernel pick(int dim, int law) {
 struct DeviceBuffers {   // frees whatever was allocated when the call leaves, on every path
     std::vector<void*> ptrs;
     hipStream_t stream = nullptr;
+    int device = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DeviceBuffers() {
+        const bool idle = stream && hipStreamSynchronize(stream) == hipSuccess;
         for (void* p : ptrs) (void)hipFree(p);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (idle) nbx::park_stream(device, stream);   // back to the pool (nbx_api.hip): a stream costs more than this call's kernels
+        else if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -244,7 +247,8 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
-    NBX_HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    d.device = device;
+    NBX_HIP_TRY(nbx::take_stream(device, &d.stream));
     NBX_HIP_TRY(hipEventCreate(&d.ev0));
     NBX_HIP_TRY(hipEventCreate(&d.ev1));
     auto dalloc = [&](void** p, size_t bytes) -> hipError_t {

@@ -9,8 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace nbx;
@@ -34,6 +36,37 @@ int fail(int code, const char* msg) {
     g_detail = msg;
     return code;
 }
+
+// Streams are the expensive part of a context on this runtime: hipStreamCreateWithFlags 1.4 ms, hipStreamDestroy 1.2-3 ms
+// (tools/ubench/api_cost.hip, profiles/r2/api_cost.txt) -- more than a whole force evaluation below N ~ 50,000, and the
+// one-shot entry points make and destroy a context per call.  A destroyed context parks its idle stream here; the next
+// context on that device takes it.  Parked streams live until the process ends.
+namespace {
+std::mutex g_stream_pool_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+constexpr size_t kStreamPoolMax = 16;
+}  // namespace
+
+hipError_t take_stream(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void park_stream(int device, hipStream_t s) {   // s is idle: the caller has synchronised it
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        if (g_stream_pool.size() < kStreamPoolMax) { g_stream_pool.emplace_back(device, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
 }  // namespace nbx
 
 namespace {
@@ -54,10 +87,49 @@ constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from
 
 namespace {
 
+constexpr size_t kArenaAlign = 256;
+size_t arena_round(size_t bytes) { return ((bytes ? bytes : 8) + kArenaAlign - 1) / kArenaAlign * kArenaAlign; }
+
+// Device memory of a context: from the creation-time arena while it lasts, otherwise an allocation of its own.
+template <typename T>
+int dev_alloc(nbx_ctx* c, T** p, size_t bytes) {
+    bytes = arena_round(bytes);
+    if (c->arena && c->arena_used + bytes <= c->arena_bytes) {
+        *p = reinterpret_cast<T*>(c->arena + c->arena_used);
+        c->arena_used += bytes;
+        return NBX_OK;
+    }
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, bytes));
+    c->extra.push_back(q);
+    *p = static_cast<T*>(q);
+    return NBX_OK;
+}
+
+// Give a buffer back before the context goes: its own allocation is freed, a piece of the arena stays with the arena
+// (only the last piece handed out can be returned to it).
+template <typename T>
+int dev_release(nbx_ctx* c, T*& p, size_t bytes) {
+    if (!p) return NBX_OK;
+    char* q = reinterpret_cast<char*>(p);
+    p = nullptr;
+    if (c->arena && q >= c->arena && q < c->arena + c->arena_bytes) {
+        if (q + arena_round(bytes) == c->arena + c->arena_used) c->arena_used -= arena_round(bytes);
+        return NBX_OK;
+    }
+    for (size_t i = 0; i < c->extra.size(); ++i)
+        if (c->extra[i] == q) { c->extra.erase(c->extra.begin() + (long)i); break; }
+    HIP_TRY(hipFree(q));
+    return NBX_OK;
+}
+
 int ensure_stage(nbx_ctx* c, size_t bytes) {
     if (bytes <= c->stage_bytes) return NBX_OK;
-    if (c->stage) { HIP_TRY(hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
-    HIP_TRY(hipMalloc((void**)&c->stage, bytes));
+    int rc = dev_release(c, c->stage, c->stage_bytes);
+    c->stage_bytes = 0;
+    if (rc) return rc;
+    rc = dev_alloc(c, &c->stage, bytes);
+    if (rc) return rc;
     c->stage_bytes = bytes;
     return NBX_OK;
 }
@@ -112,34 +184,37 @@ int ensure_acc(nbx_ctx* c) {
     // single shard of more than ~16 M bodies would ask for > 50 GB here.  Say so instead of failing in hipMalloc.
     if ((size_t)c->splits * c->dim * c->pad * sizeof(float) > ((size_t)48 << 30))
         return fail(NBX_ERR_ALLOC, "shard too large for the per-slice partial sums (12 B x slices x bodies > 48 GiB): split the bodies over more shards");
+    int rc = NBX_OK;
     if (!(c->acc && c->acc_splits_alloc >= c->splits)) {
-        if (c->acc) { HIP_TRY(hipFree(c->acc)); c->acc = nullptr; }
-        HIP_TRY(hipMalloc((void**)&c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
+        if ((rc = dev_release(c, c->acc, (size_t)c->acc_splits_alloc * c->dim * c->pad * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, &c->acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)))) return rc;
         c->acc_splits_alloc = c->splits;
     }
     if (variant_is_fast(c->variant)) {
         if (!c->cand_list) {
-            HIP_TRY(hipMalloc((void**)&c->cand_list, (size_t)c->pad * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->cand_pos, (size_t)c->dim * c->pad * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&c->bad_list, (size_t)c->pad * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->bad_flag, (size_t)c->pad * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->counters, 4 * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->src_cand_pos, (size_t)c->dim * c->n_shards * c->pad * sizeof(float)));
+            if ((rc = dev_alloc(c, &c->cand_list, (size_t)c->pad * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->cand_pos, (size_t)c->dim * c->pad * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, &c->bad_list, (size_t)c->pad * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->bad_flag, (size_t)c->pad * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->counters, 4 * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->src_cand_pos, (size_t)c->dim * c->n_shards * c->pad * sizeof(float)))) return rc;
             c->tgt_cand_valid = 0; c->bad_list_pass = -1;
         }
         if (c->hash_refine && !c->hash.keys) {
             const unsigned cap = (unsigned)c->n_shards * c->pad;
             c->hash.capacity = cap;
             c->hash.temp_bytes = hash_temp_bytes(cap);
-            HIP_TRY(hipMalloc((void**)&c->hash.keys, (size_t)cap * sizeof(unsigned long long)));
-            HIP_TRY(hipMalloc((void**)&c->hash.keys_sorted, (size_t)cap * sizeof(unsigned long long)));
-            HIP_TRY(hipMalloc((void**)&c->hash.vals, (size_t)cap * sizeof(unsigned)));
-            HIP_TRY(hipMalloc((void**)&c->hash.vals_sorted, (size_t)cap * sizeof(unsigned)));
-            HIP_TRY(hipMalloc(&c->hash.temp, c->hash.temp_bytes ? c->hash.temp_bytes : 8));
+            if ((rc = dev_alloc(c, &c->hash.keys, (size_t)cap * sizeof(unsigned long long)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.keys_sorted, (size_t)cap * sizeof(unsigned long long)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.vals, (size_t)cap * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.vals_sorted, (size_t)cap * sizeof(unsigned)))) return rc;
+            char* temp = nullptr;
+            if ((rc = dev_alloc(c, &temp, c->hash.temp_bytes))) return rc;
+            c->hash.temp = temp;
         }
         if (!(c->close_acc && c->close_splits_alloc >= c->splits)) {
-            if (c->close_acc) { HIP_TRY(hipFree(c->close_acc)); c->close_acc = nullptr; }
-            HIP_TRY(hipMalloc((void**)&c->close_acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)));
+            if ((rc = dev_release(c, c->close_acc, (size_t)c->close_splits_alloc * c->dim * c->pad * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, &c->close_acc, (size_t)c->splits * c->dim * c->pad * sizeof(float)))) return rc;
             c->close_splits_alloc = c->splits;
         }
     }
@@ -224,10 +299,17 @@ int nbx_warmup(int device) {
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));  // forces runtime + context creation
-    // a 1-body evaluation loads the code object and touches every kernel of the default path
-    const double one[7] = {1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-    double f[3];
-    return nbx_brute_force_forces(one, 1, 3, sizeof one, NBX_REFERENCE_G, device, f, nullptr);
+    // A small evaluation loads the code object and touches every kernel of the default path -- and is big enough
+    // (8,192 bodies: 448 KiB in, 192 KiB out) that the runtime sets up its host<->device copy machinery now: the first
+    // copy of more than a few KiB costs ~15 ms on this runtime (profiles/r2/api_cost.txt), which a 1-body call never meets.
+    constexpr size_t n = 8192;
+    std::vector<double> b(n * 7), f(n * 3);
+    for (size_t i = 0; i < n; ++i) {
+        double* r = &b[i * 7];
+        r[0] = 1.0e5 + 37.0 * (double)(i % 97); r[1] = 2.0e5 + 11.0 * (double)(i / 97); r[2] = 3.0e5 + (double)i;
+        r[3] = r[4] = r[5] = 0.0; r[6] = 1.0;
+    }
+    return nbx_brute_force_forces(b.data(), n, 3, 7 * sizeof(double), NBX_REFERENCE_G, device, f.data(), nullptr);
 }
 
 int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_shards, int shard) {
@@ -258,14 +340,36 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
         if (e_ != hipSuccess) { int r_ = fail_hip(e_, #expr, __FILE__, __LINE__); nbx_ctx_destroy(c); return r_; } \
     } while (0)
     CTX_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    CTX_TRY(hipGetDeviceProperties(&prop, device));
-    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CTX_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    int cus = 0;
+    CTX_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    c->num_cus = cus > 0 ? cus : 256;
+    CTX_TRY(take_stream(device, &c->own_stream));
     c->stream = c->own_stream;
-    CTX_TRY(hipMalloc((void**)&c->x64, (size_t)dim * pad * sizeof(double)));
-    CTX_TRY(hipMalloc((void**)&c->v64, (size_t)dim * pad * sizeof(double)));
-    CTX_TRY(hipMalloc((void**)&c->m64, pad * sizeof(double)));
+    {
+        // One allocation for what a default run of this shape will ask for (dev_alloc): the fp64 state, the boundary staging
+        // buffer at Body<dim>'s own stride, the partial sums of the default variant at its automatic slice count (twice:
+        // the close-set side path has its own), the close-set lists, and -- for an unsharded context, whose exchange
+        // buffers are always its own -- the fp32 source arrays.  Anything else falls through to its own allocation.
+        const size_t body = (size_t)(2 * dim + 1) * sizeof(double);
+        const int splits = auto_splits(c, c->variant);
+        size_t want = 2 * arena_round((size_t)dim * pad * sizeof(double)) + arena_round(pad * sizeof(double));
+        want += arena_round(n_total * body + 16);
+        want += 2 * arena_round((size_t)splits * dim * pad * sizeof(float));
+        want += 3 * arena_round(pad * sizeof(unsigned)) + arena_round((size_t)dim * pad * sizeof(float)) + arena_round(16)
+                + arena_round((size_t)dim * n_shards * pad * sizeof(float));
+        if (n_shards == 1) want += arena_round((size_t)dim * pad * sizeof(float)) + arena_round(pad * sizeof(float));
+        if (want <= ((size_t)64 << 30)) {   // beyond that the pieces are allocated one by one, and fail one by one
+            void* a = nullptr;
+            CTX_TRY(hipMalloc(&a, want));
+            c->arena = static_cast<char*>(a);
+            c->arena_bytes = want;
+        }
+    }
+#define CTX_ALLOC(ptr, bytes) do { int r_ = dev_alloc(c, &(ptr), (bytes)); if (r_) { nbx_ctx_destroy(c); return r_; } } while (0)
+    CTX_ALLOC(c->x64, (size_t)dim * pad * sizeof(double));
+    CTX_ALLOC(c->v64, (size_t)dim * pad * sizeof(double));
+    CTX_ALLOC(c->m64, pad * sizeof(double));
+#undef CTX_ALLOC
     c->ev0.assign(kEventPairs, nullptr);  // event pairs are created on first use
     c->ev1.assign(kEventPairs, nullptr);
 #undef CTX_TRY
@@ -277,33 +381,19 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (!c) return NBX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->own_gather) { if (c->pos_all) (void)hipFree(c->pos_all); if (c->mass_all) (void)hipFree(c->mass_all); }
-    if (c->x64) (void)hipFree(c->x64);
-    if (c->v64) (void)hipFree(c->v64);
-    if (c->m64) (void)hipFree(c->m64);
-    if (c->acc) (void)hipFree(c->acc);
-    if (c->cand_list) (void)hipFree(c->cand_list);
-    if (c->cand_pos) (void)hipFree(c->cand_pos);
-    if (c->bad_list) (void)hipFree(c->bad_list);
-    if (c->bad_flag) (void)hipFree(c->bad_flag);
-    if (c->counters) (void)hipFree(c->counters);
-    if (c->close_acc) (void)hipFree(c->close_acc);
-    if (c->src_cand_pos) (void)hipFree(c->src_cand_pos);
-    if (c->hash.keys) (void)hipFree(c->hash.keys);
-    if (c->hash.keys_sorted) (void)hipFree(c->hash.keys_sorted);
-    if (c->hash.vals) (void)hipFree(c->hash.vals);
-    if (c->hash.vals_sorted) (void)hipFree(c->hash.vals_sorted);
-    if (c->hash.temp) (void)hipFree(c->hash.temp);
+    for (void* p : c->extra) (void)hipFree(p);   // every device buffer is a piece of the arena or one of these
+    if (c->arena) (void)hipFree(c->arena);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
     if (c->counters_ev) (void)hipEventDestroy(c->counters_ev);
-    if (c->phi) (void)hipFree(c->phi);
     if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);
     if (c->bulk0) (void)hipEventDestroy(c->bulk0);
     if (c->bulk1) (void)hipEventDestroy(c->bulk1);
-    if (c->stage) (void)hipFree(c->stage);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->own_stream) {
+        if (hipStreamSynchronize(c->own_stream) == hipSuccess) park_stream(c->device, c->own_stream);
+        else (void)hipStreamDestroy(c->own_stream);
+    }
     delete c;
     return NBX_OK;
 }
@@ -318,8 +408,8 @@ int nbx_ctx_set_gather_buffers(nbx_ctx* c, void* pos_all, void* mass_all) {
     if (!c || !pos_all || !mass_all) return fail(NBX_ERR_INVALID, "null argument");
     if (c->uploaded) return fail(NBX_ERR_STATE, "gather buffers must be set before upload");
     if (c->own_gather) {
-        if (c->pos_all) (void)hipFree(c->pos_all);
-        if (c->mass_all) (void)hipFree(c->mass_all);
+        (void)dev_release(c, c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float));
+        (void)dev_release(c, c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float));
     }
     c->pos_all = (float*)pos_all;
     c->mass_all = (float*)mass_all;
@@ -344,8 +434,8 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     int rc = set_device(c);
     if (rc) return rc;
     if (!c->pos_all) {
-        HIP_TRY(hipMalloc((void**)&c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)));
+        if ((rc = dev_alloc(c, &c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, &c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)))) return rc;
         c->own_gather = true;
     }
     // Preconditions of the fast (unguarded) force path, checked on the caller's array while it is
@@ -704,7 +794,7 @@ int nbx_ctx_energy(nbx_ctx* c, double G, double* kinetic, double* potential) {
     if (!c->uploaded) return fail(NBX_ERR_STATE, "nothing uploaded");
     int rc = set_device(c);
     if (rc) return rc;
-    if (!c->phi) HIP_TRY(hipMalloc((void**)&c->phi, (size_t)kPhiSlices * c->pad * sizeof(float)));
+    if (!c->phi && (rc = dev_alloc(c, &c->phi, (size_t)kPhiSlices * c->pad * sizeof(float)))) return rc;
     AccelLaunch L = {};
     L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->phi; L.pad = c->pad; L.count = (unsigned)c->count;
     L.tgt_chunk = c->shard; L.chunk_first = 0; L.vchunks = c->n_shards; L.chunk_skip = INT_MAX; L.splits = kPhiSlices;

@@ -64,6 +64,13 @@ struct nbx_ctx {
     bool extent_ok = false;     // every |coordinate| <= kOneRcpMaxCoord at upload (one-reciprocal kernel allowed)
     bool force_exact = false;   // masses too large for the kTiny bias, or most of the shard in the close set
     int variant_req = -1;       // what the caller asked for (-1: library default)
+    // device memory: ONE allocation made at creation holds everything a default run needs (a one-shot call otherwise pays
+    // ~17 hipMalloc and as many synchronising hipFree, several milliseconds, for work that takes microseconds at the
+    // reference sweep's small sizes); what does not fit -- hash-mode workspace, a later change of tuning -- is allocated
+    // on its own and remembered in `extra`
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    std::vector<void*> extra;
     // boundary staging
     double* stage = nullptr;
     size_t stage_bytes = 0;
@@ -78,6 +85,10 @@ namespace nbx {
 // error plumbing of the C ABI (nbx_api.hip): record the detail text, return the status code
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
 int fail(int code, const char* msg);
+// non-blocking streams from a per-device pool of parked ones (nbx_api.hip: creating and destroying a stream costs
+// milliseconds on this runtime); park_stream takes an IDLE stream
+hipError_t take_stream(int device, hipStream_t* out);
+void park_stream(int device, hipStream_t s);
 }  // namespace nbx
 
 #define NBX_HIP_TRY(expr)                                                           \

@@ -203,7 +203,7 @@ int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, si
         int rc = nbx_ctx_create(&k.ctx, k.device, dim, n_total, n_ranks, r);
         if (rc) { nbx_node_destroy(nd); return rc; }
         NODE_TRY(hipSetDevice(k.device));
-        NODE_TRY(hipStreamCreateWithFlags(&k.comm, hipStreamNonBlocking));
+        NODE_TRY(take_stream(k.device, &k.comm));
         NODE_TRY(hipEventCreateWithFlags(&k.ready, hipEventDisableTiming));
         NODE_TRY(hipEventCreateWithFlags(&k.exchanged, hipEventDisableTiming));
         for (int q = 0; q < n_ranks; ++q) {  // direct xGMI copies where the devices allow it; ignored otherwise
@@ -243,7 +243,10 @@ int nbx_node_destroy(nbx_node* nd) {
         if (k.nccl && nd->rccl.CommDestroy) (void)nd->rccl.CommDestroy(k.nccl);
         if (k.ready) (void)hipEventDestroy(k.ready);
         if (k.exchanged) (void)hipEventDestroy(k.exchanged);
-        if (k.comm) (void)hipStreamDestroy(k.comm);
+        if (k.comm) {   // synchronised above; parked for the next node / context on this device (nbx_api.hip)
+            if (hipStreamQuery(k.comm) == hipSuccess) park_stream(k.device, k.comm);
+            else (void)hipStreamDestroy(k.comm);
+        }
         (void)nbx_ctx_destroy(k.ctx);
     }
     (void)hipGetLastError();
