@@ -353,7 +353,7 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
         const size_t body = (size_t)(2 * dim + 1) * sizeof(double);
         const int splits = auto_splits(c, c->variant);
         size_t want = 2 * arena_round((size_t)dim * pad * sizeof(double)) + arena_round(pad * sizeof(double));
-        want += arena_round(n_total * body + 16);
+        want += arena_round(n_total * body + 16) + arena_round(3 * sizeof(unsigned long long));
         want += 2 * arena_round((size_t)splits * dim * pad * sizeof(float));
         want += 3 * arena_round(pad * sizeof(unsigned)) + arena_round((size_t)dim * pad * sizeof(float)) + arena_round(16)
                 + arena_round((size_t)dim * n_shards * pad * sizeof(float));
@@ -369,6 +369,7 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     CTX_ALLOC(c->x64, (size_t)dim * pad * sizeof(double));
     CTX_ALLOC(c->v64, (size_t)dim * pad * sizeof(double));
     CTX_ALLOC(c->m64, pad * sizeof(double));
+    CTX_ALLOC(c->facts, 3 * sizeof(unsigned long long));
 #undef CTX_ALLOC
     c->ev0.assign(kEventPairs, nullptr);  // event pairs are created on first use
     c->ev1.assign(kEventPairs, nullptr);
@@ -438,32 +439,6 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
         if ((rc = dev_alloc(c, &c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)))) return rc;
         c->own_gather = true;
     }
-    // Preconditions of the fast (unguarded) force path, checked on the caller's array while it is
-    // borrowed: every mass small enough for the kTiny bias, and the close set a small part of the shard.
-    {
-        const char* base = static_cast<const char*>(bodies);
-        const size_t lo = (size_t)c->shard * c->shard_len;
-        double mmax = 0.0, cmax = 0.0;
-        size_t close = 0;
-        for (size_t i = 0; i < c->n_total; ++i) {
-            const double* b = reinterpret_cast<const double*>(base + i * stride_bytes);
-            const double m = b[2 * c->dim] < 0 ? -b[2 * c->dim] : b[2 * c->dim];
-            if (!(m <= mmax)) mmax = m;  // also catches NaN
-            for (int k = 0; k < c->dim; ++k) { const double v = b[k] < 0 ? -b[k] : b[k]; if (!(v <= cmax)) cmax = v; }
-            if (i >= lo && i < lo + c->count) {
-                double cm = b[0] < 0 ? -b[0] : b[0];
-                for (int k = 1; k < c->dim; ++k) { const double v = b[k] < 0 ? -b[k] : b[k]; if (v < cm) cm = v; }
-                if (cm < (double)kCloseCoord) ++close;
-            }
-        }
-        c->mass_max = mmax;
-        c->force_exact = !(mmax <= kFastMaxMass);
-        // More than 1/8 of the shard in the candidate set (a small-coordinate system): the candidates x candidates check
-        // would be O(N^2); the fast path then refines through sorted cells, provided the probe below finds few enough
-        // targets that really own a close pair.
-        c->hash_refine = !c->force_exact && close * 8 > c->count;
-        c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
-    }
     const size_t bytes = c->n_total * stride_bytes;
     rc = ensure_stage(c, bytes ? bytes : 8);
     if (rc) return rc;
@@ -472,8 +447,27 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     p.raw = c->stage; p.stride_d = stride_bytes / sizeof(double); p.n_total = c->n_total;
     p.shard_len = c->shard_len; p.pad = c->pad; p.n_shards = c->n_shards; p.shard = c->shard; p.dim = c->dim;
     p.pos_all = c->pos_all; p.mass_all = c->mass_all; p.x64 = c->x64; p.v64 = c->v64; p.m64 = c->m64;
+    p.facts = c->facts;
+    HIP_TRY(hipMemsetAsync(c->facts, 0, 3 * sizeof(unsigned long long), c->stream));
     HIP_TRY(launch_pack(p, c->stream));
+    unsigned long long facts[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(facts, c->facts, sizeof facts, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
+    // Preconditions of the fast (unguarded) force path, from what the pack pass saw: every mass small enough for the
+    // kTiny bias (a NaN fails the comparison), and the close set a small part of the shard.
+    {
+        double mmax, cmax;
+        std::memcpy(&mmax, &facts[0], sizeof mmax);
+        std::memcpy(&cmax, &facts[1], sizeof cmax);
+        const size_t close = (size_t)facts[2];
+        c->mass_max = mmax;
+        c->force_exact = !(mmax <= kFastMaxMass);
+        // More than 1/8 of the shard in the candidate set (a small-coordinate system): the candidates x candidates check
+        // would be O(N^2); the fast path then refines through sorted cells, provided the probe below finds few enough
+        // targets that really own a close pair.
+        c->hash_refine = !c->force_exact && close * 8 > c->count;
+        c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
+    }
     c->uploaded = true;
     c->have_accel = false;
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;

@@ -21,6 +21,7 @@ struct nbx_ctx {
     bool own_gather = true;
     // own shard
     double *x64 = nullptr, *v64 = nullptr, *m64 = nullptr;
+    unsigned long long* facts = nullptr;   // [3] what pack_kernel learnt about the uploaded bodies (PackArgs::facts)
     float* acc = nullptr;
     int acc_splits_alloc = 0;
     // fast-path workspace (close-set pipeline) and its preconditions

@@ -180,6 +180,8 @@ struct PackArgs {
     double* x64;           // [dim][pad]   own shard
     double* v64;           // [dim][pad]
     double* m64;           // [pad]
+    unsigned long long* facts;  // [3], zeroed by the caller: bit patterns of max |mass| and max |coordinate| over all bodies
+                                // (NaN sorts above everything), and the own shard's count of close-set candidates
 };
 hipError_t launch_pack(const PackArgs& p, hipStream_t stream);
 

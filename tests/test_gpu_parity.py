@@ -280,6 +280,15 @@ def test_fast_path_preconditions_fall_back_to_guarded_kernel(nbx, oracle):
         assert "exact" in c.effective_tuning()[0]
         c.compute_accel()
         assert_force_parity(c.forces(oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "huge mass")
+    # (1b) the scan runs on the device (pack pass) over every shard's bodies: a negative huge mass in another shard, or a NaN
+    #      mass anywhere but last, must be seen as well
+    for bad in (-3.0e12, float("nan")):
+        b = oracle.round_inputs_to_f32(oracle.generate(5, n, dim))
+        b[n // 2 + 11, -1] = bad
+        with nbx.Context(n, dim, n_shards=3, shard=0) as c:
+            c.upload(b)
+            c.set_tuning(0, fast[0])
+            assert "exact" in c.effective_tuning()[0], bad
     # (2) a whole system inside the candidate region (small box) no longer forces the guarded kernel: see
     #     test_small_coordinate_systems_keep_the_fast_path (sorted-cell refinement); a system in which MOST targets really
     #     own a sub-threshold pair still does
