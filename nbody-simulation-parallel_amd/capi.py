@@ -33,6 +33,7 @@ ABI = [
     ("nbx_last_error_detail", _c.c_char_p, []),
     ("nbx_device_count", _i, [_pi]),
     ("nbx_warmup", _i, [_i]),
+    ("nbx_release_cached", _i, []),
     ("nbx_brute_force_forces", _i, [_vp, _sz, _i, _sz, _d, _i, _vp, _pf]),
     ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
     ("nbx_leaf_pair_forces", _i, [_vp, _sz, _i, _sz, _vp, _vp, _sz, _vp, _vp, _i, _d, _i, _vp, _pf]),
@@ -106,6 +107,8 @@ def load_library(path: Optional[str] = None):
         fn.argtypes = args
     if path is None:
         _lib = lib
+        import atexit
+        atexit.register(lib.nbx_release_cached)   # parked streams / RCCL communicators go back before the runtime does
     return lib
 
 

@@ -55,95 +55,186 @@ struct LeafArgs {
     double* __restrict__ acc;          // [dim][slots]
 };
 
+// Weight of d = p_j - p_i in the law's sum for ONE pair, every special case included: m_j / r^4 for an ordinary pair.
 template <int D, int LAW>
-__device__ __forceinline__ void leaf_interact(float4 s, float ix, float iy, float iz, float& ax, float& ay, float& az) {
-    const float dx = s.x - ix, dy = s.y - iy, dz = (D == 3) ? s.z - iz : 0.0f;
-    float r2 = __builtin_fmaf(dy, dy, dx * dx);
-    if (D == 3) r2 = __builtin_fmaf(dz, dz, r2);
-    float w;   // weight of d: m_j / r^4 for an ordinary pair
+__device__ __forceinline__ float leaf_weight(float r2, float mj, float dx, float dy, float dz) {
     if (LAW == NBX_LAW_BRUTE) {
         const float g = (r2 < kR2SkipF) ? __builtin_inff() : r2;           // methods.cpp:24
         const float ri = __builtin_amdgcn_rcpf(g);
-        w = s.w * ri * ri;
+        return mj * ri * ri;
     } else if (LAW == NBX_LAW_TREE_LEAF) {
         // "same position" (every |d_k| <= 1e-9) implies r2 <= 3e-18 < 1e-9: one test covers both skips
         const float g = (r2 < kTreeSkipF) ? __builtin_inff() : r2;
         const float ri = __builtin_amdgcn_rcpf(g);
-        w = s.w * ri * ri;
+        return mj * ri * ri;
     } else {
-        const bool same = __builtin_fabsf(dx) <= kSameF && __builtin_fabsf(dy) <= kSameF && (D == 2 || __builtin_fabsf(dz) <= kSameF);
         if (r2 < kSmoothF) {   // rare: smoothed magnitude, unsmoothed direction (fmm_parlay.cpp:1010-1020, vector.h:93-97)
+            const bool same = __builtin_fabsf(dx) <= kSameF && __builtin_fabsf(dy) <= kSameF && (D == 2 || __builtin_fabsf(dz) <= kSameF);
             const float r2s = r2 + 1.0e-10f;                                                   // epsilon^2, epsilon = 1e-5
-            const float mag = s.w * __builtin_amdgcn_rcpf(r2s) * __builtin_amdgcn_rsqf(r2s);   // m / (r2s * sqrt(r2s))
+            const float mag = mj * __builtin_amdgcn_rcpf(r2s) * __builtin_amdgcn_rsqf(r2s);    // m / (r2s * sqrt(r2s))
             const float inv = (r2 < kNormZeroF) ? 0.0f : __builtin_amdgcn_rsqf(r2);               // normalized(): 0 below 1e-10
-            w = same ? 0.0f : mag * inv;
-        } else {
-            const float ri = __builtin_amdgcn_rcpf(r2);
-            w = s.w * ri * ri;
+            return same ? 0.0f : mag * inv;
         }
+        const float ri = __builtin_amdgcn_rcpf(r2);
+        return mj * ri * ri;
     }
-    ax = __builtin_fmaf(w, dx, ax);
-    ay = __builtin_fmaf(w, dy, ay);
-    if (D == 3) az = __builtin_fmaf(w, dz, az);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Below this r^2 a pair leaves the plain m_j d / r^4 form under the law (skip or smoothing); leaf_weight decides how.
+template <int LAW>
+__device__ __forceinline__ constexpr float law_special_below() {
+    return LAW == NBX_LAW_BRUTE ? kR2SkipF : LAW == NBX_LAW_TREE_LEAF ? kTreeSkipF : kSmoothF;
+}
+
+// One workgroup = up to BLOCK targets of one leaf against that leaf's source list.
+//  * The list is read ONCE, by the lanes in parallel (lane k: list entry k -> that source leaf's slot range), and turned
+//    into one stream of source bodies by a prefix sum over the leaf sizes in LDS; tiles are then cut from the STREAM
+//    (BLOCK consecutive stream positions, whatever leaves they fall in), not from single leaves.  Walking the list leaf
+//    by leaf cost a chain of three dependent loads per ~30-body tile and left half of every tile empty.
+//  * Two SOURCES per lane and iteration, as packed fp32 pairs (v_pk_add/fma/mul_f32: 3 + 3 + 2 + 3 packed instructions and
+//    two v_rcp_f32 for two pairs, where one source at a time took 12 scalar ones and a v_rcp per pair).  The tile is
+//    staged in LDS as source PAIRS {xa,xb,ya,yb},{za,zb,ma,mb}, so each ds_read_b128 lands in aligned register pairs.
+//  * The law's special cases (skip / smoothing below ~1e-5 separation, and a body meeting itself in its own leaf) are
+//    rare: one v_cmp per pair and a wave-wide vote; only a wave in which some lane sees r^2 below the law's threshold
+//    takes the guarded scalar weights (leaf_weight) for that source pair -- which is every pair of the target's own leaf
+//    (each source there is some lane's own body) and next to nothing else.
+//  * Leaves are small (the reference caps them at 100 bodies; a uniform grid at 32 per leaf leaves half of a wave64 idle
+//    with one lane per target): a block whose targets fill at most half / a quarter of the lanes gives each target 2 / 4
+//    lanes, which split the source pairs of every tile between them; their fp64 sums meet in LDS at the end, in lane
+//    group order (deterministic).
 template <int D, int LAW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[BLOCK];
+    __shared__ float4 tile[BLOCK];          // BLOCK/2 source pairs x 2 float4
+    __shared__ double red[3][BLOCK];
+    __shared__ uint32_t seg_end[BLOCK];     // stream position one past the last body of list entry k (inclusive prefix sum)
+    __shared__ uint32_t seg_first[BLOCK];   // slot of stream position 0 if entry k started there: slot = seg_first[k] + position
     const unsigned tid = threadIdx.x;
     const TargetBlock tb = a.blocks[blockIdx.x];
-    const bool valid = tid < tb.count;
-    const uint32_t slot = tb.first + (valid ? tid : 0u);
+    const unsigned lgP = (tb.count * 4u <= (unsigned)BLOCK) ? 2u : (tb.count * 2u <= (unsigned)BLOCK) ? 1u : 0u;
+    const unsigned P = 1u << lgP, W = (unsigned)BLOCK >> lgP;   // lanes per target, targets per block
+    const unsigned t = tid & (W - 1u), g = tid / W;
+    const bool valid = t < tb.count;
+    const uint32_t slot = tb.first + (valid ? t : 0u);
     const float ix = a.x[slot], iy = a.x[(size_t)a.slots + slot], iz = (D == 3) ? a.x[2 * (size_t)a.slots + slot] : 0.0f;
+    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
     double ox = 0.0, oy = 0.0, oz = 0.0;
-    // Walk the leaf's source list as one stream of tiles (<= BLOCK bodies of one source leaf each), software-pipelined: the
-    // next tile's global loads are issued before the current tile is consumed, so their latency hides behind the pair loop
-    // (leaves are small: without this every tile paid a full L2 round trip in front of ~30 sources of arithmetic).
-    // All of it is workgroup-uniform control flow.
-    uint32_t e = a.list_offsets[tb.leaf];
+    float* const tf = reinterpret_cast<float*>(tile);
+    const unsigned wr = (tid >> 1) * 8u + (tid & 1u);      // source tid = half (tid & 1) of pair tid / 2
     const uint32_t e1 = a.list_offsets[tb.leaf + 1];
-    uint32_t base = 0, end = 0;
-    auto advance = [&]() -> bool {             // move to the next non-empty tile of the stream
-        base += BLOCK;
-        while (base >= end) {
-            if (e >= e1) return false;
-            const uint32_t s = a.list_sources[e++];
-            base = a.leaf_offsets[s];
-            end = a.leaf_offsets[s + 1];
+    // the list in chunks of BLOCK entries (one chunk for every list the reference's trees produce); all workgroup-uniform
+    for (uint32_t e0 = a.list_offsets[tb.leaf]; e0 < e1; e0 += (uint32_t)BLOCK) {
+        const unsigned n_ent = (e1 - e0 < (uint32_t)BLOCK) ? (unsigned)(e1 - e0) : (unsigned)BLOCK;
+        uint32_t first = 0, len = 0;
+        if (tid < n_ent) {
+            const uint32_t s = a.list_sources[e0 + tid];
+            first = a.leaf_offsets[s];
+            len = a.leaf_offsets[s + 1] - first;
         }
-        return true;
-    };
-    auto load = [&](uint32_t cnt) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < cnt) {
-            const uint32_t j = base + tid;
-            v.x = a.x[j];
-            v.y = a.x[(size_t)a.slots + j];
-            v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
-            v.w = a.m[j];
-        }
-        return v;
-    };
-    bool has = advance();
-    uint32_t cnt = has ? ((end - base < (uint32_t)BLOCK) ? end - base : (uint32_t)BLOCK) : 0u;
-    float4 nxt = has ? load(cnt) : make_float4(0.f, 0.f, 0.f, 0.f);
-    while (has) {
-        const uint32_t cur = cnt;
-        __syncthreads();                                       // previous tile fully consumed
-        tile[tid] = nxt;
+        __syncthreads();                                   // the previous chunk's last tile and tables are done with
+        seg_end[tid] = len;
         __syncthreads();
-        has = advance();
-        if (has) {
-            cnt = (end - base < (uint32_t)BLOCK) ? end - base : (uint32_t)BLOCK;
-            nxt = load(cnt);                                   // in flight while this tile is consumed
+        for (unsigned d = 1; d < (unsigned)BLOCK; d <<= 1) {   // inclusive prefix sum (Hillis-Steele)
+            const uint32_t add = (tid >= d) ? seg_end[tid - d] : 0u;
+            __syncthreads();
+            seg_end[tid] += add;
+            __syncthreads();
         }
-        // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
-        // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-        float ax = 0.f, ay = 0.f, az = 0.f;
-        for (uint32_t j = 0; j < cur; ++j) leaf_interact<D, LAW>(tile[j], ix, iy, iz, ax, ay, az);
-        ox += (double)ax; oy += (double)ay; oz += (double)az;
+        const uint32_t my_end = seg_end[tid];
+        seg_first[tid] = first - (my_end - len);
+        __syncthreads();
+        const uint32_t total = seg_end[BLOCK - 1];         // bodies in this chunk's stream
+        // Tiles of the stream, software-pipelined: the next tile's global loads are issued before the current tile is
+        // consumed, so their latency hides behind the pair loop.
+        unsigned k = 0;                                    // this lane's list entry; only ever moves forward
+        auto load = [&](uint32_t pos) -> float4 {
+            // positions past the stream's end stage a massless body far away: it pads the last tile to whole pairs and
+            // contributes exactly 0 under every law (r^2 ~ 1e36 is finite in fp32, w = 0 * r^-4)
+            float4 v = make_float4(1.0e18f, 1.0e18f, (D == 3) ? 1.0e18f : 0.0f, 0.f);
+            if (pos < total) {
+                while (pos >= seg_end[k]) ++k;             // empty leaves are stepped over here as well
+                const uint32_t j = seg_first[k] + pos;
+                v.x = a.x[j];
+                v.y = a.x[(size_t)a.slots + j];
+                v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
+                v.w = a.m[j];
+            }
+            return v;
+        };
+        float4 nxt = load(tid);
+        for (uint32_t pos0 = 0; pos0 < total; pos0 += (uint32_t)BLOCK) {
+            const uint32_t cur = (total - pos0 < (uint32_t)BLOCK) ? total - pos0 : (uint32_t)BLOCK;
+            __syncthreads();                                   // previous tile fully consumed
+            tf[wr] = nxt.x; tf[wr + 2] = nxt.y; tf[wr + 4] = nxt.z; tf[wr + 6] = nxt.w;
+            __syncthreads();
+            if (pos0 + (uint32_t)BLOCK < total) nxt = load(pos0 + (uint32_t)BLOCK + tid);   // in flight while this tile is consumed
+            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
+            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
+            f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
+            // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
+            // the tile up to a multiple of P past the last real one is real or pad, never stale
+            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) >> lgP;
+            const float4* src = tile + 2u * g;
+            // one source pair {A, B} against this lane's target: d, r^2, then the weights (plain form, or the guarded one
+            // when the wave's vote says some lane is below the law's threshold) and the accumulation
+            struct Pair { f2 dx, dy, dz, r2, sm; };
+            auto geometry = [&](const float4 A, const float4 B) -> Pair {
+                Pair q;
+                q.sm = f2{B.z, B.w};
+                q.dx = f2{A.x, A.y} - ix2;
+                q.dy = f2{A.z, A.w} - iy2;
+                q.dz = (D == 3) ? f2{B.x, B.y} - iz2 : f2{0.f, 0.f};
+                q.r2 = q.dx * q.dx;
+                q.r2 = __builtin_elementwise_fma(q.dy, q.dy, q.r2);
+                if (D == 3) q.r2 = __builtin_elementwise_fma(q.dz, q.dz, q.r2);
+                return q;
+            };
+            auto special = [&](const Pair& q) -> unsigned long long {
+                return __builtin_amdgcn_ballot_w64(q.r2.x < law_special_below<LAW>()) | __builtin_amdgcn_ballot_w64(q.r2.y < law_special_below<LAW>());
+            };
+            auto guarded = [&](const Pair& q) -> f2 {
+                float ra = q.r2.x, rb = q.r2.y;
+                asm volatile("" : "+v"(ra), "+v"(rb));   // keeps the guarded form's compares in this (rare) branch: hipcc hoists them otherwise
+                return f2{leaf_weight<D, LAW>(ra, q.sm.x, q.dx.x, q.dy.x, q.dz.x), leaf_weight<D, LAW>(rb, q.sm.y, q.dx.y, q.dy.y, q.dz.y)};
+            };
+            auto plain = [&](const Pair& q) -> f2 {
+                f2 w = {__builtin_amdgcn_rcpf(q.r2.x), __builtin_amdgcn_rcpf(q.r2.y)};
+                w = w * w;
+                return w * q.sm;
+            };
+            auto add = [&](const Pair& q, const f2 w) {
+                ax = __builtin_elementwise_fma(w, q.dx, ax);
+                ay = __builtin_elementwise_fma(w, q.dy, ay);
+                if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
+            };
+            unsigned it = 0;
+            for (; it + 1u < trips; it += 2u, src += 4u * P) {   // two source pairs per trip: one vote, independent chains
+                const Pair q0 = geometry(src[0], src[1]), q1 = geometry(src[2u * P], src[2u * P + 1u]);
+                f2 w0, w1;
+                if (__builtin_expect((special(q0) | special(q1)) != 0ull, 0)) { w0 = guarded(q0); w1 = guarded(q1); }     // wave-uniform, rare
+                else { w0 = plain(q0); w1 = plain(q1); }
+                add(q0, w0);
+                add(q1, w1);
+            }
+            if (it < trips) {
+                const Pair q0 = geometry(src[0], src[1]);
+                const f2 w0 = __builtin_expect(special(q0) != 0ull, 0) ? guarded(q0) : plain(q0);
+                add(q0, w0);
+            }
+            ox += (double)ax.x + (double)ax.y;
+            oy += (double)ay.x + (double)ay.y;
+            oz += (double)az.x + (double)az.y;
+        }
     }
-    if (valid) {
+    if (P > 1u) {                                              // block-uniform
+        __syncthreads();
+        red[0][tid] = ox; red[1][tid] = oy; red[2][tid] = oz;
+        __syncthreads();
+        if (g == 0u)
+            for (unsigned q = 1; q < P; ++q) { ox += red[0][q * W + t]; oy += red[1][q * W + t]; oz += red[2][q * W + t]; }
+    }
+    if (valid && g == 0u) {
         a.acc[slot] = ox;
         a.acc[(size_t)a.slots + slot] = oy;
         if (D == 3) a.acc[2 * (size_t)a.slots + slot] = oz;

@@ -67,6 +67,20 @@ void park_stream(int device, hipStream_t s) {   // s is idle: the caller has syn
     }
     (void)hipStreamDestroy(s);
 }
+
+void release_parked_streams() {
+    std::vector<std::pair<int, hipStream_t>> parked;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        parked.swap(g_stream_pool);
+    }
+    int before = 0;
+    const bool have = hipGetDevice(&before) == hipSuccess;
+    for (auto& e : parked)
+        if (hipSetDevice(e.first) == hipSuccess) (void)hipStreamDestroy(e.second);
+    if (have) (void)hipSetDevice(before);
+    (void)hipGetLastError();
+}
 }  // namespace nbx
 
 namespace {
@@ -290,6 +304,12 @@ int nbx_device_count(int* count) {
     if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount", __FILE__, __LINE__);
     *count = n;
     return n > 0 ? NBX_OK : fail(NBX_ERR_NO_DEVICE, "hipGetDeviceCount returned 0 devices");
+}
+
+int nbx_release_cached(void) {
+    release_parked_communicators();
+    release_parked_streams();
+    return NBX_OK;
 }
 
 int nbx_warmup(int device) {

@@ -90,6 +90,8 @@ int fail(int code, const char* msg);
 // milliseconds on this runtime); park_stream takes an IDLE stream
 hipError_t take_stream(int device, hipStream_t* out);
 void park_stream(int device, hipStream_t s);
+void release_parked_streams();
+void release_parked_communicators();   // nbx_node.hip
 }  // namespace nbx
 
 #define NBX_HIP_TRY(expr)                                                           \

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -52,6 +53,20 @@ struct Rccl {
 };
 constexpr int kNcclFloat32 = 7;
 
+// Communicators of destroyed nodes, kept for the next node over the same device list: ncclCommInitAll is the most
+// expensive call of this library by orders of magnitude, and the one-shot entry of the harness (BruteForce_HIP_x<G>)
+// builds a node per call.  `verified` travels with the set: the poisoned-buffer self-check of the exchange is a check of
+// the transport, made once per communicator set.  A set goes back only from a node on which no RCCL call failed.
+struct CommSet {
+    std::vector<int> devices;
+    std::vector<void*> comms;
+    bool verified = false;
+};
+std::mutex g_comm_mu;
+std::vector<CommSet> g_comm_cache;
+int (*g_comm_destroy)(void*) = nullptr;
+constexpr size_t kCommCacheMax = 4;
+
 struct Rank {
     nbx_ctx* ctx = nullptr;
     int device = 0;
@@ -72,11 +87,13 @@ struct nbx_node {
     Rccl rccl;
     bool uploaded = false;
     bool exchange_verified = false;   // the RCCL exchange passed its poisoned-buffer self-check
+    bool rccl_failed = false;         // an RCCL call returned an error: the communicators are not reused
 };
 
 namespace {
 
 int nccl_fail(nbx_node* nd, int rc, const char* what) {
+    nd->rccl_failed = true;
     char buf[256];
     std::snprintf(buf, sizeof buf, "%s failed: %s", what, nd->rccl.GetErrorString ? nd->rccl.GetErrorString(rc) : "rccl error");
     return fail(NBX_ERR_HIP, buf);
@@ -173,6 +190,21 @@ int evaluate(nbx_node* nd) {
 
 }  // namespace
 
+namespace nbx {
+void release_parked_communicators() {
+    std::vector<CommSet> parked;
+    {
+        std::lock_guard<std::mutex> lock(g_comm_mu);
+        parked.swap(g_comm_cache);
+    }
+    if (!g_comm_destroy) return;
+    for (CommSet& set : parked)
+        for (size_t r = 0; r < set.comms.size(); ++r)
+            if (hipSetDevice(set.devices[r]) == hipSuccess) (void)g_comm_destroy(set.comms[r]);
+    (void)hipGetLastError();
+}
+}  // namespace nbx
+
 extern "C" {
 
 int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, size_t n_total, int exchange) {
@@ -221,8 +253,22 @@ int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, si
         std::vector<void*> comms((size_t)n_ranks, nullptr);
         std::vector<int> devs((size_t)n_ranks);
         for (int r = 0; r < n_ranks; ++r) devs[r] = nd->ranks[r].device;
-        const int rc = nd->rccl.CommInitAll(comms.data(), n_ranks, devs.data());
-        if (rc) { int e = nccl_fail(nd, rc, "ncclCommInitAll"); nbx_node_destroy(nd); return e; }
+        bool cached = false;
+        {
+            std::lock_guard<std::mutex> lock(g_comm_mu);
+            for (size_t i = 0; i < g_comm_cache.size(); ++i)
+                if (g_comm_cache[i].devices == devs) {
+                    comms = g_comm_cache[i].comms;
+                    nd->exchange_verified = g_comm_cache[i].verified;
+                    g_comm_cache.erase(g_comm_cache.begin() + (long)i);
+                    cached = true;
+                    break;
+                }
+        }
+        if (!cached) {
+            const int rc = nd->rccl.CommInitAll(comms.data(), n_ranks, devs.data());
+            if (rc) { int e = nccl_fail(nd, rc, "ncclCommInitAll"); nbx_node_destroy(nd); return e; }
+        }
         for (int r = 0; r < n_ranks; ++r) nd->ranks[r].nccl = comms[r];
     }
     *out = nd;
@@ -236,6 +282,20 @@ int nbx_node_destroy(nbx_node* nd) {
         (void)hipSetDevice(k.device);
         (void)nbx_ctx_synchronize(k.ctx);
         if (k.comm) (void)hipStreamSynchronize(k.comm);
+    }
+    // a complete, healthy communicator set is parked for the next node over these devices; otherwise it is destroyed
+    bool park = nd->exchange == NBX_EXCHANGE_RCCL && !nd->rccl_failed && nd->rccl.CommDestroy;
+    for (Rank& k : nd->ranks) park = park && k.ctx && k.nccl;
+    if (park) {
+        CommSet set;
+        for (Rank& k : nd->ranks) { set.devices.push_back(k.device); set.comms.push_back(k.nccl); }
+        set.verified = nd->exchange_verified;
+        std::lock_guard<std::mutex> lock(g_comm_mu);
+        if (g_comm_cache.size() < kCommCacheMax) {
+            g_comm_destroy = nd->rccl.CommDestroy;
+            g_comm_cache.push_back(std::move(set));
+            for (Rank& k : nd->ranks) k.nccl = nullptr;
+        }
     }
     for (Rank& k : nd->ranks) {
         if (!k.ctx) continue;

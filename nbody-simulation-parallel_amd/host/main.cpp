@@ -137,6 +137,10 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
         out << method.banner << std::endl;
         if (method.threaded) out << "Using " << omp_get_max_threads() << " threads..." << std::endl;
         Forces forces;
+        // the CPU rows before this one may have kept the device idle for minutes: its clocks and the runtime's copy queues
+        // are woken outside the timed call, like the start-up in main() (measured: 96 ms instead of 3 ms at N = 100,000
+        // after 25 s of CPU rows)
+        if (!method.threaded && method.label == hip_label && run_cpu_bf) warm_up_hip();
         const long long us = safely_execute(log, method.label, [&] { forces = method.solve(); return 0; });
         if (us >= 0) {
             const double seconds = static_cast<double>(us) / 1e6;
@@ -401,5 +405,6 @@ int main(int argc, char* argv[]) {
         std::cerr << "Unknown error occurred" << std::endl;
         return 1;
     }
+    release_hip_caches();
     return 0;
 }

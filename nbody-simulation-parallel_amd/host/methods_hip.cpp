@@ -36,10 +36,29 @@ int device_ordinal() {
 const HipRunInfo& last_hip_run_info() { return g_info; }
 bool warm_up_hip() {
     bool ok = true;
-    if (g_devices.size() > 1) for (int d : g_devices) ok = (nbx_warmup(d) == NBX_OK) && ok;
-    else ok = nbx_warmup(device_ordinal()) == NBX_OK;
+    if (g_devices.size() > 1) {
+        for (int d : g_devices) ok = (nbx_warmup(d) == NBX_OK) && ok;
+        // and the node layer: the first node over these devices builds the RCCL communicators (by far the most expensive
+        // call of the library) and proves the exchange on a poisoned buffer; the library keeps the set for the nodes the
+        // timed calls build
+        constexpr size_t n = 8192;
+        std::vector<double> b(n * 7), f(n * 3);
+        for (size_t i = 0; i < n; ++i) {
+            double* r = &b[i * 7];
+            r[0] = 1.0e5 + 37.0 * (double)(i % 97); r[1] = 2.0e5 + 11.0 * (double)(i / 97); r[2] = 3.0e5 + (double)i;
+            r[3] = r[4] = r[5] = 0.0; r[6] = 1.0;
+        }
+        NodeHandle node;
+        int rc = nbx_node_create(&node.h, (int)g_devices.size(), g_devices.data(), 3, n, NBX_EXCHANGE_AUTO);
+        if (!rc) rc = nbx_node_upload_bodies(node.h, b.data(), 7 * sizeof(double));
+        if (!rc) rc = nbx_node_compute_forces(node.h, NBX_REFERENCE_G, f.data());
+        ok = ok && rc == NBX_OK;
+    } else {
+        ok = nbx_warmup(device_ordinal()) == NBX_OK;
+    }
     return ok;
 }
+void release_hip_caches() { (void)nbx_release_cached(); }
 int hip_device_count() {
     int n = 0;
     return nbx_device_count(&n) == NBX_OK ? n : 0;

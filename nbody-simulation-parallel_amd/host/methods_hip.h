@@ -69,6 +69,8 @@ const HipRunInfo& last_hip_run_info();
 // Bring the device(s) up before anything is timed (HIP runtime, code-object load): nbx_warmup.
 // Returns false (and changes nothing) if no device is usable -- the solver calls will then throw.
 bool warm_up_hip();
+// Give back what the library keeps between calls (idle streams, RCCL communicators): nbx_release_cached.  Before exit.
+void release_hip_caches();
 
 // Number of HIP devices visible (0 when there is none or the runtime fails).
 int hip_device_count();

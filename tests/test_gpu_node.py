@@ -79,3 +79,32 @@ def test_rccl_single_rank_and_argument_checks(nbx, oracle):
         nbx.Node(n, dim, [0, 99])                                # no such device
     lib = nbx.load_library()
     assert lib.nbx_node_step(None, 1.0, 1.0, 1) == 1 and lib.nbx_node_destroy(None) == 0
+
+
+def test_parked_streams_and_communicators_are_reused_and_released(nbx, oracle):
+    """Destroyed contexts / nodes park their streams and RCCL communicators for the next ones (nbx_release_cached gives
+    them back): many one-shot calls, a node that takes the previous node's communicator, a release in between -- results
+    stay the same throughout."""
+    import time
+    n, dim = 2000, 3
+    b = oracle.round_inputs_to_f32(oracle.generate(35, n, dim))
+    lib = nbx.load_library()
+    first = nbx.brute_force_hip_n_body(b)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        assert np.array_equal(nbx.brute_force_hip_n_body(b), first)
+    per_call = (time.perf_counter() - t0) / 40
+    print(f"one-shot call at N={n}: {per_call * 1e3:.3f} ms")
+    # (3.2 ms per call when every call made and destroyed a stream; no assertion on a shared box's clock)
+    for round_ in range(3):
+        with nbx.Node(n, dim, [0], nbx.EXCHANGE_RCCL) as node:      # rounds 1, 2 take the communicator parked by the one before
+            node.upload(b)
+            assert np.array_equal(node.forces(oracle.G), first)
+        if round_ == 1:
+            assert lib.nbx_release_cached() == 0                   # round 2 has to build a new one
+    with nbx.Node(n, dim, [0, 0, 0], nbx.EXCHANGE_PEER_COPY) as node:   # comm streams come from the pool as well
+        node.upload(b)
+        f3 = node.forces(oracle.G)
+    assert_force_parity(f3, oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "three virtual ranks after a release")
+    assert lib.nbx_release_cached() == 0
+    assert np.array_equal(nbx.brute_force_hip_n_body(b), first)
