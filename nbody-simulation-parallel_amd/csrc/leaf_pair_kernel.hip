@@ -29,6 +29,7 @@ namespace {
 // (the mean leaf of the reference's trees is well under 100 bodies, methods.h:26) so that fewer lanes idle
 constexpr int kLeafBlock = 128;
 constexpr int kLeafBlockSmall = 64;
+constexpr int kMaxLanesPerTarget = 8;   // a block of few targets gives each up to this many lanes (they split the sources)
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
 constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
@@ -106,22 +107,29 @@ __device__ __forceinline__ constexpr float law_special_below() {
 //    group order (deterministic).
 template <int D, int LAW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[BLOCK];          // BLOCK/2 source pairs x 2 float4
+    __shared__ float4 tile[BLOCK + 2 * kMaxLanesPerTarget];   // BLOCK/2 source pairs x 2 float4, + pad pairs past the end
     __shared__ double red[3][BLOCK];
     __shared__ uint32_t seg_end[BLOCK];     // stream position one past the last body of list entry k (inclusive prefix sum)
     __shared__ uint32_t seg_first[BLOCK];   // slot of stream position 0 if entry k started there: slot = seg_first[k] + position
     const unsigned tid = threadIdx.x;
     const TargetBlock tb = a.blocks[blockIdx.x];
-    const unsigned lgP = (tb.count * 4u <= (unsigned)BLOCK) ? 2u : (tb.count * 2u <= (unsigned)BLOCK) ? 1u : 0u;
-    const unsigned P = 1u << lgP, W = (unsigned)BLOCK >> lgP;   // lanes per target, targets per block
-    const unsigned t = tid & (W - 1u), g = tid / W;
-    const bool valid = t < tb.count;
+    // lanes per target: as many whole groups of `count` lanes as the block holds (21 targets in a wave64: 3 lanes each)
+    const unsigned W = tb.count ? tb.count : 1u;
+    const unsigned fit = (unsigned)BLOCK / W;
+    const unsigned P = fit < (unsigned)kMaxLanesPerTarget ? fit : (unsigned)kMaxLanesPerTarget;
+    const unsigned t = tid % W, g_raw = tid / W;
+    const bool valid = g_raw < P;                              // lanes left over compute along with group 0, unused
+    const unsigned g = valid ? g_raw : 0u;
     const uint32_t slot = tb.first + (valid ? t : 0u);
     const float ix = a.x[slot], iy = a.x[(size_t)a.slots + slot], iz = (D == 3) ? a.x[2 * (size_t)a.slots + slot] : 0.0f;
     const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
     double ox = 0.0, oy = 0.0, oz = 0.0;
     float* const tf = reinterpret_cast<float*>(tile);
     const unsigned wr = (tid >> 1) * 8u + (tid & 1u);      // source tid = half (tid & 1) of pair tid / 2
+    // the lane groups stride through the tile's pairs P at a time: the last trip may reach up to P - 1 pairs past the
+    // tile -- massless bodies far away, staged once
+    if (tid < 2u * (unsigned)kMaxLanesPerTarget)
+        tile[BLOCK + tid] = (tid & 1u) ? make_float4((D == 3) ? 1.0e18f : 0.0f, (D == 3) ? 1.0e18f : 0.0f, 0.f, 0.f) : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 1.0e18f);
     const uint32_t e1 = a.list_offsets[tb.leaf + 1];
     // the list in chunks of BLOCK entries (one chunk for every list the reference's trees produce); all workgroup-uniform
     for (uint32_t e0 = a.list_offsets[tb.leaf]; e0 < e1; e0 += (uint32_t)BLOCK) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
             f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
             // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
             // the tile up to a multiple of P past the last real one is real or pad, never stale
-            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) >> lgP;
+            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) / P;
             const float4* src = tile + 2u * g;
             // one source pair {A, B} against this lane's target: d, r^2, then the weights (plain form, or the guarded one
             // when the wave's vote says some lane is below the law's threshold) and the accumulation
@@ -331,10 +339,26 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
     // block size by the mean leaf: up to 80 bodies per leaf one wave64 per block wastes fewer lanes than two
     const uint32_t block = (nonempty && slots / nonempty <= 80) ? (uint32_t)kLeafBlockSmall : (uint32_t)kLeafBlock;
+    // Target blocks.  A block of c targets runs floor(block / c) lanes per target (kernel), so c just above block / 2 wastes
+    // almost half the lanes: such a piece is cut in two when that fills the lanes better by more than the cost of staging
+    // the source stream a second time (~15 %): 33..42 targets in a wave64 become two blocks at 3 lanes per target.
+    auto lane_use = [&](uint32_t c) -> double {
+        uint32_t lanes = block / c;
+        if (lanes > (uint32_t)kMaxLanesPerTarget) lanes = (uint32_t)kMaxLanesPerTarget;
+        return (double)(c * lanes) / (double)block;
+    };
     std::vector<TargetBlock> blocks;
     for (size_t l = 0; l < n_leaves; ++l)
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block)
-            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block});
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block) {
+            const uint32_t c = (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block;
+            const uint32_t half = (c + 1) / 2;
+            if (c >= 2 && lane_use(half) > 1.15 * lane_use(c)) {
+                blocks.push_back(TargetBlock{(uint32_t)l, f, half});
+                blocks.push_back(TargetBlock{(uint32_t)l, f + half, c - half});
+            } else {
+                blocks.push_back(TargetBlock{(uint32_t)l, f, c});
+            }
+        }
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;

@@ -92,6 +92,39 @@ def test_ragged_structure_and_close_pairs(nbx, oracle):
     assert np.abs(f0[4]).max() > 1e3 * np.abs(f1[4]).max()          # the tree-leaf law drops the 2e-5 pair
 
 
+@pytest.mark.parametrize("dim", (3, 2))
+@pytest.mark.parametrize("big", (False, True))
+def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
+    """Target leaves of every size from 1 to 70 (small: wave64 blocks) or 1 to 258 in steps of 3 (big: 128-lane blocks), so
+    that every lanes-per-target count, every split of a piece in two and every partly filled last tile occurs; source lists
+    of 1 to 300 entries with repeats and empty leaves in them (longer than one block of list entries: chunked), odd and even
+    stream lengths; all three laws."""
+    sizes = list(range(1, 71)) if not big else list(range(1, 260, 3))
+    sizes += [0, 0]                                                  # two empty leaves, also as sources
+    rng = np.random.default_rng(90 + dim + 2 * big)
+    order = rng.permutation(len(sizes))
+    sizes = [sizes[i] for i in order]
+    n = sum(sizes) + 17                                              # 17 bodies in no leaf
+    b = oracle.generate(91 + dim, n, dim)
+    b[:, :dim] /= 1.0e3                                              # a box of 1e4: denser, larger pair terms
+    b = oracle.round_inputs_to_f32(b)
+    lo = np.concatenate([[0], np.cumsum(sizes)])
+    lb = rng.permutation(n)[:lo[-1]]
+    n_leaves = len(sizes)
+    lists = []
+    for t in range(n_leaves):
+        k = [1, 2, 3, 27, 64, 65, 129, 300][t % 8] if sizes[t] else 5
+        lists.append(rng.integers(0, n_leaves, k))
+        if t % 3 == 0:
+            lists[-1][0] = t                                         # own leaf on the list: every body meets itself
+    so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    ss = np.concatenate(lists)
+    leaves = (lo, lb, so, ss)
+    assert (np.mean([s for s in sizes if s]) > 80) == big           # which block size the library picks
+    for law, name in LAWS:
+        _check(nbx, oracle, b, leaves, law, f"every block shape, law {name}, D={dim}, big={big}")
+
+
 def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
     b = oracle.generate(1, 10, 3)
     ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
