@@ -11,6 +11,18 @@
 #   SIZES="1000 10000" GPU_COUNTS="1 2" DIMS="3" ACC_SIZES="1000" tools/run_sweep.sh
 set -uo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
+# OpenMP rows: without OMP_NUM_THREADS the runtime starts one thread per visible hardware thread, and a container that
+# shows 256 of them but grants 16 CPUs of bandwidth (cgroup cpu.max) then spends its time throttled -- a 0.2 ms row
+# reads 200 ms.  Default to the CPUs the box really grants.
+if [ -z "${OMP_NUM_THREADS:-}" ]; then
+  cpus="$(nproc)"
+  if [ -r /sys/fs/cgroup/cpu.max ] && read -r quota period < /sys/fs/cgroup/cpu.max && [ "$quota" != "max" ] && [ "${period:-0}" -gt 0 ]; then
+    granted=$(( (quota + period - 1) / period ))
+    [ "$granted" -ge 1 ] && [ "$granted" -lt "$cpus" ] && cpus="$granted"
+  fi
+  export OMP_NUM_THREADS="$cpus"
+fi
+echo "OpenMP rows use OMP_NUM_THREADS=$OMP_NUM_THREADS"
 exe="$root/nbody_sim"
 [ -x "$exe" ] || make -C "$root" nbody_sim || { echo "Build failed. Exiting."; exit 1; }
 read -r -a sizes <<< "${SIZES:-1000 10000 100000 200000 500000 1000000 2000000 5000000}"
