@@ -47,17 +47,26 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs p) {
         const double m = real ? src[2 * p.dim] : 0.0;
         p.mass_all[(size_t)g * p.pad + l] = (float)m;
         if (g == p.shard) p.m64[l] = m;
-        if (real) {
-            // non-negative doubles order like their bit patterns, and a NaN's pattern lies above infinity's
-            atomicMax(&s_mass, (unsigned long long)__double_as_longlong(fabs(m)));
-            atomicMax(&s_coord, (unsigned long long)__double_as_longlong(cmax));
-            if (g == p.shard && cmin < (double)kCloseCoord) atomicAdd(&s_close, 1u);
+        // non-negative doubles order like their bit patterns, and a NaN's pattern lies above infinity's: maxima over the
+        // wave by butterfly shuffles, then one LDS atomic per wave (one per lane made this pass 4x longer)
+        unsigned long long mb = real ? (unsigned long long)__double_as_longlong(fabs(m)) : 0ull;
+        unsigned long long cb = real ? (unsigned long long)__double_as_longlong(cmax) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long om = __shfl_xor(mb, off), oc = __shfl_xor(cb, off);
+            mb = om > mb ? om : mb;
+            cb = oc > cb ? oc : cb;
+        }
+        const unsigned long long votes = __ballot(real && g == p.shard && cmin < (double)kCloseCoord);
+        if ((threadIdx.x & 63u) == 0u) {
+            if (mb) atomicMax(&s_mass, mb);
+            if (cb) atomicMax(&s_coord, cb);
+            if (votes) atomicAdd(&s_close, (unsigned)__popcll(votes));
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (s_mass) atomicMax(&p.facts[0], s_mass);
-        if (s_coord) atomicMax(&p.facts[1], s_coord);
+        if (s_mass > *(volatile unsigned long long*)&p.facts[0]) atomicMax(&p.facts[0], s_mass);     // same economy at L2
+        if (s_coord > *(volatile unsigned long long*)&p.facts[1]) atomicMax(&p.facts[1], s_coord);
         if (s_close) atomicAdd(&p.facts[2], (unsigned long long)s_close);
     }
 }
