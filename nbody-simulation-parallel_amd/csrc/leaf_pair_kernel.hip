@@ -8,13 +8,15 @@
 //
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
 // forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
-// leaf order as SoA fp32 (coalesced streams), and the work is target-leaf-major: one 128-lane workgroup (two
-// wave64; one wave64 when the mean leaf holds <= 80 bodies) owns up to 128 (64) targets of ONE leaf -- one target per lane, fp32 tile sums flushed into fp64 second-level
-// accumulators -- and walks that leaf's source-leaf list, staging each source leaf through LDS in tiles of 128 bodies
-// {x,y,z,m}; all lanes read the same LDS address (ds_read_b128 broadcast).  No atomics, a fixed summation order
-// (list order, then leaf order), every output written once.  Leaves are small (the reference caps them at 100 bodies,
-// methods.h:26), so the launch is thousands of short workgroups: latency-bound on the lists, not VALU-bound like the
-// brute-force kernel; HBM traffic is 16 B per (target block, source body) served mostly from L2.
+// leaf order as SoA fp32 (coalesced streams), and the work is target-leaf-major: one workgroup (one wave64 when the mean
+// leaf holds <= 80 bodies, else two) owns up to 64 (128) targets of ONE leaf and walks that leaf's source-leaf list as one
+// stream of bodies staged through LDS in tiles of one body per lane {x,y,z,m}; fp32 sums per tile, flushed into fp64
+// second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
+// once.  The comment at the kernel says how the lanes share the work.  Leaves are small (the reference caps them at 100
+// bodies, methods.h:26), so the launch is tens of thousands of short workgroups; HBM traffic is 16 B per (target block,
+// source body) served mostly from L2.  With one target per lane every source costs the wave one 16-byte LDS broadcast
+// (8 LDS clocks) against 36 VALU issue cycles: four SIMDs keep the CU's LDS port ~90 % busy, which is what bounds the
+// kernel now (tiles of 256 bodies instead of 64 changed nothing: measured).
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 
