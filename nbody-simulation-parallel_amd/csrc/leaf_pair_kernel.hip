@@ -330,12 +330,14 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     }
     for (size_t e = 0; e < n_list; ++e)
         if (list_sources[e] >= n_leaves) return fail(NBX_ERR_INVALID, "list_sources entry out of range");
-    for (size_t i = 0; i < n * (size_t)dim; ++i) forces_out[i] = 0.0;   // bodies in no leaf: zero force
     int ndev = 0;
     int rc = nbx_device_count(&ndev);
     if (rc != NBX_OK) return rc;
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
-    if (slots == 0) return NBX_OK;
+    if (slots == 0) {   // no leaf holds a body: every force is zero (otherwise the device array, zeroed there, is copied out whole)
+        for (size_t i = 0; i < n * (size_t)dim; ++i) forces_out[i] = 0.0;
+        return NBX_OK;
+    }
 
     size_t nonempty = 0;
     for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
@@ -368,25 +370,25 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(nbx::take_stream(device, &d.stream));
     NBX_HIP_TRY(hipEventCreate(&d.ev0));
     NBX_HIP_TRY(hipEventCreate(&d.ev1));
-    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
-        if (e == hipSuccess) d.ptrs.push_back(*p);
-        return e;
-    };
-    double *raw = nullptr, *acc = nullptr, *dforces = nullptr;
-    float *x = nullptr, *m = nullptr;
-    uint32_t *d_lo = nullptr, *d_lb = nullptr, *d_so = nullptr, *d_ss = nullptr;
-    TargetBlock* d_blocks = nullptr;
-    NBX_HIP_TRY(dalloc((void**)&raw, n * stride_bytes));
-    NBX_HIP_TRY(dalloc((void**)&x, (size_t)dim * slots * sizeof(float)));
-    NBX_HIP_TRY(dalloc((void**)&m, slots * sizeof(float)));
-    NBX_HIP_TRY(dalloc((void**)&acc, (size_t)dim * slots * sizeof(double)));
-    NBX_HIP_TRY(dalloc((void**)&dforces, n * (size_t)dim * sizeof(double)));
-    NBX_HIP_TRY(dalloc((void**)&d_lo, (n_leaves + 1) * sizeof(uint32_t)));
-    NBX_HIP_TRY(dalloc((void**)&d_lb, slots * sizeof(uint32_t)));
-    NBX_HIP_TRY(dalloc((void**)&d_so, (n_leaves + 1) * sizeof(uint32_t)));
-    NBX_HIP_TRY(dalloc((void**)&d_ss, n_list * sizeof(uint32_t)));
-    NBX_HIP_TRY(dalloc((void**)&d_blocks, blocks.size() * sizeof(TargetBlock)));
+    // one allocation for the call's ten device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
+    const size_t sizes[10] = {n * stride_bytes, (size_t)dim * slots * sizeof(float), slots * sizeof(float), (size_t)dim * slots * sizeof(double),
+                              n * (size_t)dim * sizeof(double), (n_leaves + 1) * sizeof(uint32_t), slots * sizeof(uint32_t),
+                              (n_leaves + 1) * sizeof(uint32_t), n_list * sizeof(uint32_t), blocks.size() * sizeof(TargetBlock)};
+    size_t offs[10], total_bytes = 0;
+    for (int i = 0; i < 10; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
+    char* arena = nullptr;
+    NBX_HIP_TRY(hipMalloc((void**)&arena, total_bytes));
+    d.ptrs.push_back(arena);
+    double* raw = reinterpret_cast<double*>(arena + offs[0]);
+    float* x = reinterpret_cast<float*>(arena + offs[1]);
+    float* m = reinterpret_cast<float*>(arena + offs[2]);
+    double* acc = reinterpret_cast<double*>(arena + offs[3]);
+    double* dforces = reinterpret_cast<double*>(arena + offs[4]);
+    uint32_t* d_lo = reinterpret_cast<uint32_t*>(arena + offs[5]);
+    uint32_t* d_lb = reinterpret_cast<uint32_t*>(arena + offs[6]);
+    uint32_t* d_so = reinterpret_cast<uint32_t*>(arena + offs[7]);
+    uint32_t* d_ss = reinterpret_cast<uint32_t*>(arena + offs[8]);
+    TargetBlock* d_blocks = reinterpret_cast<TargetBlock*>(arena + offs[9]);
     NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
     NBX_HIP_TRY(hipMemcpyAsync(d_lo, leaf_offsets, (n_leaves + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     NBX_HIP_TRY(hipMemcpyAsync(d_lb, leaf_bodies, slots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
