@@ -14,9 +14,9 @@
 // second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
 // once.  The comment at the kernel says how the lanes share the work.  Leaves are small (the reference caps them at 100
 // bodies, methods.h:26), so the launch is tens of thousands of short workgroups; HBM traffic is 16 B per (target block,
-// source body) served mostly from L2.  With one target per lane every source costs the wave one 16-byte LDS broadcast
-// (8 LDS clocks) against 36 VALU issue cycles: four SIMDs keep the CU's LDS port ~90 % busy, which is what bounds the
-// kernel now (tiles of 256 bodies instead of 64 changed nothing: measured).
+// source body) served mostly from L2.  VALU-issue-bound (counters: profiles/r2/pmc_leaf_pair_kernel.txt): 76 % of the
+// instructions are the pair loop, the rest stages tiles and flushes sums; tiles of 256 bodies instead of 64, or half the
+// LDS reads, changed nothing measurable.
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 
