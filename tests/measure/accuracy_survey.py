@@ -25,10 +25,15 @@ threading.Thread(target=_heartbeat, daemon=True).start()
 cases = [(65536, 3, None, 2), (65536, 2, None, 2), (1 << 20, 3, 2048, 3), (1 << 20, 2, 1024, 3)]
 if "full20" in sys.argv[1:]:        # every one of the 1,048,576 bodies against the oracle: ~5 minutes of host time at 16 threads
     cases = [(1 << 20, 3, None, 3)]
+elif "plummer22" in sys.argv[1:]:   # BASELINE config 5's own input (N = 4,194,304 Plummer sphere, tests/test_gpu_config5.py): 32,768 rows
+    cases = [(1 << 22, 3, 32768, 5)]
 elif len(sys.argv) > 1:
     cases = [c for c in cases if str(c[0]) in sys.argv[1:]]
 for n, dim, nrows, seed in cases:
-    b = o.round_inputs_to_f32(o.generate(seed, n, dim))
+    if "plummer22" in sys.argv[1:]:
+        b = o.round_inputs_to_f32(nbx.plummer_bodies(n, 3, seed=seed, a=1.0e5, total_mass=1.0e12))
+    else:
+        b = o.round_inputs_to_f32(o.generate(seed, n, dim))
     with nbx.Context(n, dim) as c:
         c.upload(b)
         c.compute_accel()

@@ -251,6 +251,9 @@ def have_reference() -> bool:
 # with a correctly rounded reciprocal, so it is the arithmetic, not the kernel).
 # KAPPA_WELL = 4: (T2) then follows from the measured backward maxima (2.1e-6 * 4 < 1e-5) instead of relying
 # on the worst backward error never meeting a moderately ill-conditioned body.
+# TOL_BACKWARD is a 3.5-sigma bound (worst case of one pair term + 3.5 sigma of the ~512 fp32 additions it rides through),
+# asserted on what the tests compare; the analytic worst case is 274 unit roundoffs = 1.6e-5.  Largest value seen: 3.7e-6 on
+# 32,641 sampled rows of BASELINE config 5 (N = 2^22 Plummer sphere; profiles/r2/accuracy_config5_32768rows.jsonl).
 TOL_REL = 1.0e-5
 TOL_BACKWARD = 4.0e-6
 KAPPA_WELL = 4.0
