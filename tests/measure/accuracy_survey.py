@@ -36,6 +36,8 @@ for n, dim, nrows, seed in cases:
         b = o.round_inputs_to_f32(o.generate(seed, n, dim))
     with nbx.Context(n, dim) as c:
         c.upload(b)
+        if os.environ.get("NBX_SURVEY_VARIANT"):      # e.g. lds_t1_w8_exact_u8: fp64 second-level sums, for comparison
+            c.set_tuning(0, nbx.variants().index(os.environ["NBX_SURVEY_VARIANT"]))
         c.compute_accel()
         f = c.forces(o.G)
         name = c.effective_tuning()[0]
