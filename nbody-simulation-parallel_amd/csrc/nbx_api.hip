@@ -274,6 +274,95 @@ int set_device(const nbx_ctx* c) {
 
 }  // namespace
 
+namespace nbx {
+
+// Upload, first half: the caller's Body<D> array (or, only_own, just this shard's slice of it) to the staging buffer, the
+// pack pass, and what that pass learnt about the bodies (facts: PackArgs::facts).  With only_own the other chunks of the
+// exchange buffers are NOT filled: the node layer brings them in from the ranks that own them (nbx_node.hip), so that R
+// ranks move the array over the host links once instead of R times.
+int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3]) {
+    if (!c || (!bodies && c->n_total)) return fail(NBX_ERR_INVALID, "null argument");
+    const size_t min_stride = (size_t)(2 * c->dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->pos_all) {
+        if ((rc = dev_alloc(c, &c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, &c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)))) return rc;
+        c->own_gather = true;
+    }
+    const size_t first = only_own ? (size_t)c->shard * c->shard_len : 0;
+    const size_t nb = only_own ? c->count : c->n_total;
+    const size_t bytes = nb * stride_bytes;
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(c->stage, static_cast<const char*>(bodies) + first * stride_bytes, bytes, hipMemcpyHostToDevice, c->stream));
+    PackArgs p;
+    p.raw = c->stage; p.stride_d = stride_bytes / sizeof(double); p.n_total = c->n_total;
+    p.shard_len = c->shard_len; p.pad = c->pad; p.n_shards = c->n_shards; p.shard = c->shard; p.dim = c->dim;
+    p.pos_all = c->pos_all; p.mass_all = c->mass_all; p.x64 = c->x64; p.v64 = c->v64; p.m64 = c->m64;
+    p.only_own = only_own ? 1 : 0; p.n_own = c->count;
+    p.facts = c->facts;
+    HIP_TRY(hipMemsetAsync(c->facts, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(launch_pack(p, c->stream));
+    HIP_TRY(hipMemcpyAsync(facts, c->facts, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
+    return NBX_OK;
+}
+
+// Upload, second half: the preconditions of the fast (unguarded) force path from the facts -- facts[0], facts[1] over ALL
+// bodies (the node layer combines its ranks' values), facts[2] this shard's candidate count -- and, for a small-coordinate
+// system, the probe.  Every chunk of the exchange buffers must be in place by now.
+int upload_finish(nbx_ctx* c, const unsigned long long facts[3]) {
+    int rc = set_device(c);
+    if (rc) return rc;
+    {
+        double mmax, cmax;
+        std::memcpy(&mmax, &facts[0], sizeof mmax);
+        std::memcpy(&cmax, &facts[1], sizeof cmax);
+        const size_t close = (size_t)facts[2];
+        c->mass_max = mmax;
+        c->force_exact = !(mmax <= kFastMaxMass);   // every mass small enough for the kTiny bias (a NaN fails the comparison)
+        // More than 1/8 of the shard in the candidate set (a small-coordinate system): the candidates x candidates check
+        // would be O(N^2); the fast path then refines through sorted cells, provided the probe below finds few enough
+        // targets that really own a close pair.
+        c->hash_refine = !c->force_exact && close * 8 > c->count;
+        c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
+    }
+    c->uploaded = true;
+    c->have_accel = false;
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    c->probe_bad = 0;
+    c->counters_pending = false; c->steps_since_poll = 0; c->last_cand = c->last_bad = 0;
+    if (c->hash_refine) {
+        // Probe: build the close-set lists once against ALL sources and read the number of bad targets back (this call
+        // synchronises anyway).  Too many (> 1/8 of the shard: the guarded side path would dominate) -> guarded kernel.
+        rc = ensure_acc(c);
+        if (rc) return rc;
+        if (variant_is_fast(c->variant)) {
+            AccelLaunch L = {};
+            L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
+            L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
+            L.cand_list = c->cand_list; L.cand_pos = c->cand_pos; L.bad_list = c->bad_list; L.bad_flag = c->bad_flag;
+            L.counters = c->counters; L.close_acc = c->close_acc; L.src_cand_pos = c->src_cand_pos;
+            L.n_total = c->n_total; L.shard_len = c->shard_len; L.n_chunks = c->n_shards;
+            L.pass = NBX_SRC_ALL; L.cacheable = 0; L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
+            L.chunk_skip = INT_MAX; L.chunk_first = 0; L.vchunks = c->n_shards; L.hash = c->hash; L.lists_only = 1;
+            HIP_TRY(launch_accel(c->dim, L, c->stream));
+            unsigned counts[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(counts, c->counters, sizeof counts, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->probe_bad = counts[1];
+            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+            if ((size_t)counts[1] * 8 > c->count) { c->force_exact = true; c->hash_refine = false; }
+        }
+    }
+    return NBX_OK;
+}
+
+}  // namespace nbx
+
 extern "C" {
 
 int nbx_abi_version(void) { return NBX_ABI_VERSION; }
@@ -448,75 +537,10 @@ int nbx_ctx_gather_layout(const nbx_ctx* c, size_t* shard_len, size_t* shard_pad
 }
 
 int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
-    if (!c || (!bodies && c->n_total)) return fail(NBX_ERR_INVALID, "null argument");
-    const size_t min_stride = (size_t)(2 * c->dim + 1) * sizeof(double);
-    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
-        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
-    int rc = set_device(c);
-    if (rc) return rc;
-    if (!c->pos_all) {
-        if ((rc = dev_alloc(c, &c->pos_all, (size_t)c->n_shards * c->dim * c->pad * sizeof(float)))) return rc;
-        if ((rc = dev_alloc(c, &c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)))) return rc;
-        c->own_gather = true;
-    }
-    const size_t bytes = c->n_total * stride_bytes;
-    rc = ensure_stage(c, bytes ? bytes : 8);
-    if (rc) return rc;
-    if (bytes) HIP_TRY(hipMemcpyAsync(c->stage, bodies, bytes, hipMemcpyHostToDevice, c->stream));
-    PackArgs p;
-    p.raw = c->stage; p.stride_d = stride_bytes / sizeof(double); p.n_total = c->n_total;
-    p.shard_len = c->shard_len; p.pad = c->pad; p.n_shards = c->n_shards; p.shard = c->shard; p.dim = c->dim;
-    p.pos_all = c->pos_all; p.mass_all = c->mass_all; p.x64 = c->x64; p.v64 = c->v64; p.m64 = c->m64;
-    p.facts = c->facts;
-    HIP_TRY(hipMemsetAsync(c->facts, 0, 3 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(launch_pack(p, c->stream));
     unsigned long long facts[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(facts, c->facts, sizeof facts, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's host array is borrowed only for this call
-    // Preconditions of the fast (unguarded) force path, from what the pack pass saw: every mass small enough for the
-    // kTiny bias (a NaN fails the comparison), and the close set a small part of the shard.
-    {
-        double mmax, cmax;
-        std::memcpy(&mmax, &facts[0], sizeof mmax);
-        std::memcpy(&cmax, &facts[1], sizeof cmax);
-        const size_t close = (size_t)facts[2];
-        c->mass_max = mmax;
-        c->force_exact = !(mmax <= kFastMaxMass);
-        // More than 1/8 of the shard in the candidate set (a small-coordinate system): the candidates x candidates check
-        // would be O(N^2); the fast path then refines through sorted cells, provided the probe below finds few enough
-        // targets that really own a close pair.
-        c->hash_refine = !c->force_exact && close * 8 > c->count;
-        c->extent_ok = cmax <= kOneRcpMaxCoord;   // the one-reciprocal kernel's product r2a*r2b stays finite
-    }
-    c->uploaded = true;
-    c->have_accel = false;
-    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
-    c->probe_bad = 0;
-    c->counters_pending = false; c->steps_since_poll = 0; c->last_cand = c->last_bad = 0;
-    if (c->hash_refine) {
-        // Probe: build the close-set lists once against ALL sources and read the number of bad targets back (this call
-        // synchronises anyway).  Too many (> 1/8 of the shard: the guarded side path would dominate) -> guarded kernel.
-        rc = ensure_acc(c);
-        if (rc) return rc;
-        if (variant_is_fast(c->variant)) {
-            AccelLaunch L = {};
-            L.pos_all = c->pos_all; L.mass_all = c->mass_all; L.acc = c->acc; L.pad = c->pad; L.count = (unsigned)c->count;
-            L.tgt_chunk = c->shard; L.splits = c->splits; L.variant = c->variant;
-            L.cand_list = c->cand_list; L.cand_pos = c->cand_pos; L.bad_list = c->bad_list; L.bad_flag = c->bad_flag;
-            L.counters = c->counters; L.close_acc = c->close_acc; L.src_cand_pos = c->src_cand_pos;
-            L.n_total = c->n_total; L.shard_len = c->shard_len; L.n_chunks = c->n_shards;
-            L.pass = NBX_SRC_ALL; L.cacheable = 0; L.tgt_cand_valid = &c->tgt_cand_valid; L.bad_list_pass = &c->bad_list_pass;
-            L.chunk_skip = INT_MAX; L.chunk_first = 0; L.vchunks = c->n_shards; L.hash = c->hash; L.lists_only = 1;
-            HIP_TRY(launch_accel(c->dim, L, c->stream));
-            unsigned counts[3] = {0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(counts, c->counters, sizeof counts, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->probe_bad = counts[1];
-            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
-            if ((size_t)counts[1] * 8 > c->count) { c->force_exact = true; c->hash_refine = false; }
-        }
-    }
-    return NBX_OK;
+    int rc = upload_stage(c, bodies, stride_bytes, /*only_own=*/false, facts);
+    if (rc) return rc;
+    return upload_finish(c, facts);
 }
 
 int nbx_ctx_set_tuning(nbx_ctx* c, int source_splits, int variant) {

@@ -91,6 +91,10 @@ int fail(int code, const char* msg);
 hipError_t take_stream(int device, hipStream_t* out);
 void park_stream(int device, hipStream_t s);
 void release_parked_streams();
+// the two halves of nbx_ctx_upload_bodies (nbx_api.hip), apart so that the node layer can upload each rank's own shard
+// only and fill the other chunks device to device in between
+int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3]);
+int upload_finish(nbx_ctx* c, const unsigned long long facts[3]);
 void release_parked_communicators();   // nbx_node.hip
 }  // namespace nbx
 

@@ -180,6 +180,8 @@ struct PackArgs {
     double* x64;           // [dim][pad]   own shard
     double* v64;           // [dim][pad]
     double* m64;           // [pad]
+    int only_own;          // 1: `raw` holds the own shard's bodies only (n_own of them) and only the own chunk is packed
+    size_t n_own;
     unsigned long long* facts;  // [3], zeroed by the caller: bit patterns of max |mass| and max |coordinate| over all bodies
                                 // (NaN sorts above everything), and the own shard's count of close-set candidates
 };

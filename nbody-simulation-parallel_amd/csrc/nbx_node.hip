@@ -322,8 +322,15 @@ int nbx_node_exchange_mode(const nbx_node* nd, int* mode) {
 
 int nbx_node_upload_bodies(nbx_node* nd, const void* bodies, size_t stride_bytes) {
     if (!nd) return fail(NBX_ERR_INVALID, "node is null");
-    for (Rank& k : nd->ranks) {
-        int rc = nbx_ctx_upload_bodies(k.ctx, bodies, stride_bytes);  // fills every chunk of this rank's source copy
+    const int R = nd->n_ranks;
+    // Each rank moves only ITS shard of the array over its host link and packs its own chunk; the other chunks of its
+    // source copy then arrive device to device: the masses once, here, by peer copies from their owners, the positions
+    // through the same exchange every step uses.  (Every rank uploading the whole array cost R host-to-device copies of
+    // it, one after the other.)
+    std::vector<unsigned long long> facts((size_t)R * 3, 0ull);
+    for (int r = 0; r < R; ++r) {
+        Rank& k = nd->ranks[r];
+        int rc = upload_stage(k.ctx, bodies, stride_bytes, /*only_own=*/R > 1, &facts[(size_t)r * 3]);
         if (rc) return rc;
         k.pos_all = k.ctx->pos_all;
         k.chunk_floats = (size_t)nd->dim * k.ctx->pad;
@@ -331,6 +338,36 @@ int nbx_node_upload_bodies(nbx_node* nd, const void* bodies, size_t stride_bytes
     nd->uploaded = true;
     int rc = mark_ready(nd);
     if (rc) return rc;
+    if (R > 1) {
+        const size_t pad = nd->ranks[0].ctx->pad;
+        for (int r = 0; r < R; ++r) {          // owner r -> every other rank's mass chunk r
+            Rank& k = nd->ranks[r];
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            for (int q = 0; q < R; ++q) {
+                if (q == r) continue;
+                Rank& dst = nd->ranks[q];
+                NBX_HIP_TRY(hipMemcpyPeerAsync(dst.ctx->mass_all + (size_t)r * pad, dst.device, k.ctx->mass_all + (size_t)r * pad, k.device,
+                                               pad * sizeof(float), k.ctx->stream));
+            }
+        }
+        rc = start_exchange(nd);
+        if (!rc) rc = finish_exchange(nd);
+        if (!rc) rc = nbx_node_synchronize(nd);   // masses (compute streams) and positions (comm streams) are in place on every rank
+        if (!rc) rc = mark_ready(nd);
+        if (rc) return rc;
+    }
+    {
+        unsigned long long mass_max = 0ull, coord_max = 0ull;   // bit patterns of non-negative doubles order like the values
+        for (int r = 0; r < R; ++r) {
+            if (facts[(size_t)r * 3] > mass_max) mass_max = facts[(size_t)r * 3];
+            if (facts[(size_t)r * 3 + 1] > coord_max) coord_max = facts[(size_t)r * 3 + 1];
+        }
+        for (int r = 0; r < R; ++r) {
+            const unsigned long long f[3] = {mass_max, coord_max, facts[(size_t)r * 3 + 2]};
+            rc = upload_finish(nd->ranks[r].ctx, f);
+            if (rc) return rc;
+        }
+    }
     // First contact of the RCCL exchange with real hardware happens here, not silently inside a step: one
     // poisoned all-gather must restore every chunk on every rank, or the upload fails loudly.
     if (nd->exchange == NBX_EXCHANGE_RCCL && nd->n_ranks > 1 && !nd->exchange_verified) {

@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs p) {
     __shared__ unsigned s_close;
     if (threadIdx.x == 0) { s_mass = 0ull; s_coord = 0ull; s_close = 0u; }
     __syncthreads();
-    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;  // index into [n_shards][pad]
-    if (b < (size_t)p.n_shards * p.pad) {
-        const int g = (int)(b / p.pad);
-        const size_t l = b - (size_t)g * p.pad;
-        const size_t id = (size_t)g * p.shard_len + l;
-        const bool real = (l < p.shard_len) && (id < p.n_total);
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;  // index into [n_shards][pad], or into the own chunk's [pad]
+    if (b < (p.only_own ? (size_t)p.pad : (size_t)p.n_shards * p.pad)) {
+        const int g = p.only_own ? p.shard : (int)(b / p.pad);
+        const size_t l = p.only_own ? b : b - (size_t)g * p.pad;
+        const size_t id = p.only_own ? l : (size_t)g * p.shard_len + l;          // index into raw
+        const bool real = p.only_own ? (l < p.n_own) : ((l < p.shard_len) && (id < p.n_total));
         const double* __restrict__ src = p.raw + id * p.stride_d;
         double cmin = 0.0, cmax = 0.0;
         for (int k = 0; k < p.dim; ++k) {
@@ -184,7 +184,7 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 hipError_t launch_pack(const PackArgs& p, hipStream_t stream) {
-    const size_t total = (size_t)p.n_shards * p.pad;
+    const size_t total = p.only_own ? (size_t)p.pad : (size_t)p.n_shards * p.pad;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, p);
     return hipGetLastError();
