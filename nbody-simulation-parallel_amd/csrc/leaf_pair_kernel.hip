@@ -173,6 +173,11 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
             return v;
         };
         float4 nxt = load(tid);
+        // fp32 sums run over up to 256 terms per lane (as in the brute-force kernel's tiles) before they are flushed into
+        // the fp64 accumulators: with P lanes per target that is several tiles -- a flush per 64-body tile was 6
+        // conversions and 6 fp64 additions against as little as 8 trips of pair arithmetic
+        f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
+        unsigned pending = 0;                                  // terms in the fp32 sums since the last flush
         for (uint32_t pos0 = 0; pos0 < total; pos0 += (uint32_t)BLOCK) {
             const uint32_t cur = (total - pos0 < (uint32_t)BLOCK) ? total - pos0 : (uint32_t)BLOCK;
             __syncthreads();                                   // previous tile fully consumed
@@ -181,7 +186,6 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
             if (pos0 + (uint32_t)BLOCK < total) nxt = load(pos0 + (uint32_t)BLOCK + tid);   // in flight while this tile is consumed
             // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
             // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-            f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
             // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
             // the tile up to a multiple of P past the last real one is real or pad, never stale
             const unsigned trips = (((cur + 1u) >> 1) + P - 1u) / P;
@@ -232,9 +236,14 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
                 const f2 w0 = __builtin_expect(special(q0) != 0ull, 0) ? guarded(q0) : plain(q0);
                 add(q0, w0);
             }
-            ox += (double)ax.x + (double)ax.y;
-            oy += (double)ay.x + (double)ay.y;
-            oz += (double)az.x + (double)az.y;
+            pending += 2u * trips;
+            if (pending + (unsigned)BLOCK > 256u || pos0 + (uint32_t)BLOCK >= total) {   // workgroup-uniform
+                ox += (double)ax.x + (double)ax.y;
+                oy += (double)ay.x + (double)ay.y;
+                oz += (double)az.x + (double)az.y;
+                ax = ay = az = f2{0.f, 0.f};
+                pending = 0;
+            }
         }
     }
     if (P > 1u) {                                              // block-uniform
