@@ -8,7 +8,7 @@
 //
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
 // forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
-// leaf order as SoA fp32 (coalesced streams), and the work is target-leaf-major: one workgroup (one wave64 when the mean
+// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: one workgroup (one wave64 when the mean
 // leaf holds <= 80 bodies, else two) owns up to 64 (128) targets of ONE leaf and walks that leaf's source-leaf list as one
 // stream of bodies staged through LDS in tiles of one body per lane {x,y,z,m}; fp32 sums per tile, flushed into fp64
 // second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
@@ -48,8 +48,7 @@ struct TargetBlock {
 };
 
 struct LeafArgs {
-    const float* __restrict__ x;       // [dim][slots] leaf-ordered positions
-    const float* __restrict__ m;       // [slots]
+    const float4* __restrict__ xm;     // [slots] leaf-ordered {x, y, z (0 in 2D), m}: one 16-byte load stages a body
     uint32_t slots;
     const uint32_t* __restrict__ leaf_offsets;
     const uint32_t* __restrict__ list_offsets;
@@ -123,7 +122,8 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
     const bool valid = g_raw < P;                              // lanes left over compute along with group 0, unused
     const unsigned g = valid ? g_raw : 0u;
     const uint32_t slot = tb.first + (valid ? t : 0u);
-    const float ix = a.x[slot], iy = a.x[(size_t)a.slots + slot], iz = (D == 3) ? a.x[2 * (size_t)a.slots + slot] : 0.0f;
+    const float4 me = a.xm[slot];
+    const float ix = me.x, iy = me.y, iz = (D == 3) ? me.z : 0.0f;
     const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
     double ox = 0.0, oy = 0.0, oz = 0.0;
     float* const tf = reinterpret_cast<float*>(tile);
@@ -165,10 +165,7 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
             if (pos < total) {
                 while (pos >= seg_end[k]) ++k;             // empty leaves are stepped over here as well
                 const uint32_t j = seg_first[k] + pos;
-                v.x = a.x[j];
-                v.y = a.x[(size_t)a.slots + j];
-                v.z = (D == 3) ? a.x[2 * (size_t)a.slots + j] : 0.0f;
-                v.w = a.m[j];
+                v = a.xm[j];
             }
             return v;
         };
@@ -260,15 +257,14 @@ __global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
     }
 }
 
-// staged Body<D> AoS fp64 (host order) -> leaf-ordered SoA fp32
+// staged Body<D> AoS fp64 (host order) -> leaf-ordered {x, y, z, m} fp32
 __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restrict__ raw, size_t stride_d, int dim,
                                                           const uint32_t* __restrict__ leaf_bodies, uint32_t slots,
-                                                          float* __restrict__ x, float* __restrict__ m) {
+                                                          float4* __restrict__ xm) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= slots) return;
     const double* __restrict__ b = raw + (size_t)leaf_bodies[s] * stride_d;
-    for (int k = 0; k < dim; ++k) x[(size_t)k * slots + s] = (float)b[k];
-    m[s] = (float)b[2 * dim];
+    xm[s] = make_float4((float)b[0], (float)b[1], dim == 3 ? (float)b[2] : 0.0f, (float)b[2 * dim]);
 }
 
 // forces_out[body] = sign * (G m_body) * acc[slot]   (fp64; every body belongs to at most one leaf)
@@ -380,7 +376,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipEventCreate(&d.ev0));
     NBX_HIP_TRY(hipEventCreate(&d.ev1));
     // one allocation for the call's ten device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
-    const size_t sizes[10] = {n * stride_bytes, (size_t)dim * slots * sizeof(float), slots * sizeof(float), (size_t)dim * slots * sizeof(double),
+    const size_t sizes[10] = {n * stride_bytes, slots * sizeof(float4), 0, (size_t)dim * slots * sizeof(double),
                               n * (size_t)dim * sizeof(double), (n_leaves + 1) * sizeof(uint32_t), slots * sizeof(uint32_t),
                               (n_leaves + 1) * sizeof(uint32_t), n_list * sizeof(uint32_t), blocks.size() * sizeof(TargetBlock)};
     size_t offs[10], total_bytes = 0;
@@ -389,8 +385,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipMalloc((void**)&arena, total_bytes));
     d.ptrs.push_back(arena);
     double* raw = reinterpret_cast<double*>(arena + offs[0]);
-    float* x = reinterpret_cast<float*>(arena + offs[1]);
-    float* m = reinterpret_cast<float*>(arena + offs[2]);
+    float4* xm = reinterpret_cast<float4*>(arena + offs[1]);
     double* acc = reinterpret_cast<double*>(arena + offs[3]);
     double* dforces = reinterpret_cast<double*>(arena + offs[4]);
     uint32_t* d_lo = reinterpret_cast<uint32_t*>(arena + offs[5]);
@@ -407,10 +402,10 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipMemsetAsync(dforces, 0, n * (size_t)dim * sizeof(double), d.stream));
     (void)hipGetLastError();
     const unsigned gs = (unsigned)((slots + 255) / 256);
-    hipLaunchKernelGGL(leaf_gather_kernel, dim3(gs), dim3(256), 0, d.stream, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots, x, m);
+    hipLaunchKernelGGL(leaf_gather_kernel, dim3(gs), dim3(256), 0, d.stream, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots, xm);
     NBX_HIP_TRY(hipGetLastError());
     LeafArgs a;
-    a.x = x; a.m = m; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
+    a.xm = xm; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
     a.blocks = d_blocks; a.acc = acc;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
     hipLaunchKernelGGL(block == (uint32_t)kLeafBlockSmall ? pick<kLeafBlockSmall>(dim, law) : pick<kLeafBlock>(dim, law),
