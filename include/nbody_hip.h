@@ -249,8 +249,10 @@ enum { NBX_EXCHANGE_AUTO = 0, NBX_EXCHANGE_PEER_COPY = 1, NBX_EXCHANGE_RCCL = 2 
 int nbx_node_create(nbx_node** out, int n_ranks, const int* devices, int dim, size_t n_total, int exchange);
 int nbx_node_destroy(nbx_node* node);
 int nbx_node_exchange_mode(const nbx_node* node, int* mode);
-/* With the RCCL exchange and more than one rank the first upload also runs nbx_node_verify_exchange once and
- * fails (NBX_ERR_HIP, detail text) if the all-gather did not deliver every chunk. */
+/* `bodies` is the whole Body<D> array; each rank copies only its own shard of it to its device, the other chunks of its
+ * source copy arrive device to device (masses once, positions through the step's exchange).  With the RCCL exchange and
+ * more than one rank the first upload over a communicator set also runs nbx_node_verify_exchange and fails (NBX_ERR_HIP,
+ * detail text) if the all-gather did not deliver every chunk. */
 int nbx_node_upload_bodies(nbx_node* node, const void* bodies, size_t body_stride_bytes);
 /* Self-check of the position exchange: every rank's copies of the chunks it does not own are overwritten with
  * NaN, one exchange runs (RCCL all-gather or peer copies, as configured), and each copy is compared bit for bit
