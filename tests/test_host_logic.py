@@ -59,3 +59,31 @@ def test_aggregate_keeps_reference_columns_and_adds_gpu_counts(tmp_path):
     v = hip[(8, 1)]
     assert v["Virtual Ranks"] == "yes" and v["Kernel Speed-up vs 1 GPU"] == "" and v["Pair Interactions/s (kernel)"] == ""
     assert float(v["Average Runtime (s)"]) == pytest.approx(0.31) and hip[(2, 2)]["Virtual Ranks"] == "no"
+
+
+def test_shell_tools_parse_and_the_sweep_sizes_its_openmp_teams(tmp_path):
+    """tools/*.sh are syntactically valid, and run_sweep.sh does not leave the OpenMP team size to the number of visible
+    hardware threads (a container may grant far fewer CPUs than it shows: 0.2 ms rows then read 100-200 ms of throttling)."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "*.sh")))
+    assert scripts
+    for sh in scripts:
+        assert subprocess.run(["bash", "-n", sh]).returncode == 0, sh
+    # run the script's prologue only: a fake harness that reports no device and succeeds, no sizes to sweep
+    fake = tmp_path / "nbody_sim"
+    fake.write_text("#!/bin/sh\nif [ \"$1\" = --device-count ]; then echo 0; fi\nexit 0\n")
+    fake.chmod(0o755)
+    text = open(os.path.join(root, "tools", "run_sweep.sh")).read().replace('exe="$root/nbody_sim"', f'exe="{fake}"')
+    text = text.replace('python3 "$root/tools/aggregate_results.py" results', "true")
+    script = tmp_path / "run_sweep.sh"
+    script.write_text(text)
+    env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}
+    env.update(SIZES="1000", GPU_COUNTS="1", DIMS="3", ACC_SIZES="")
+    p = subprocess.run(["bash", str(script)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    line = [l for l in p.stdout.splitlines() if l.startswith("OpenMP rows use OMP_NUM_THREADS=")]
+    assert line and 1 <= int(line[0].split("=")[1]) <= (os.cpu_count() or 1)
+    p = subprocess.run(["bash", str(script)], cwd=tmp_path, env=dict(env, OMP_NUM_THREADS="3"), capture_output=True, text=True, timeout=60)
+    assert "OMP_NUM_THREADS=3" in p.stdout                       # a caller's choice is kept
