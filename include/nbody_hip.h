@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NBX_ABI_VERSION 2   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk (additions only) */
+#define NBX_ABI_VERSION 3   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only) */
 
 /* status codes */
 enum {
@@ -224,6 +224,30 @@ int nbx_ctx_set_softening(nbx_ctx* ctx, double epsilon);
  * place of v_rcp_f32 and one more multiply.  Forces, kick/drift, energy and the accuracy metric all follow the law. */
 enum { NBX_FORCE_LAW_REFERENCE = 0, NBX_FORCE_LAW_NEWTON = 1 };
 int nbx_ctx_set_law(nbx_ctx* ctx, int law);
+/* PRECISION.  The reference's arithmetic is fp64 throughout (vector.h:9-12, methods.cpp:21-37); the device's default is
+ * fp32 pair terms with the stated tolerance of DESIGN.md section 4.  Two ways to go beyond it, both on the reference law:
+ *  - the variant "strict_f64_t4" (nbx_ctx_set_tuning): EVERY pair term, the skip-rule comparison and every sum in fp64 on
+ *    the device's fp32-representable positions and masses -- agrees with brute_force_seq_n_body on the same inputs to
+ *    ~1e-13 relative; about 2.5x the default kernel's time;
+ *  - MIXED MODE, nbx_ctx_set_refine(ctx, rel_tolerance, sigma_factor): fp32 for every target, then the targets whose fp32
+ *    sum cannot be trusted to rel_tolerance are re-evaluated by the strict kernel.  The criterion (force_kernel.hip,
+ *    refine_select_kernel): the rounding error of a target's fp32 sum has standard deviation ~ c u sqrt(Q_i), u = 2^-24,
+ *    Q_i = sum over the 256-source tiles of |tile partial sum|^2 (accumulated by the fast kernel at no measurable cost);
+ *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
+ *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
+ *    calibrated default.  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
+ *    Newtonian law, or a non-fast variant.  At most 1/16 of a shard's targets (at least 4096) are re-evaluated per force
+ *    evaluation; nbx_ctx_refine_stats reports how many the rule selected and how many were re-evaluated. */
+int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);
+/* After a mixed-mode force evaluation: selected = targets the rule listed, refined = those re-evaluated in fp64
+ * (= min(selected, capacity)).  Either pointer may be NULL.  Synchronises the stream. */
+int nbx_ctx_refine_stats(nbx_ctx* ctx, unsigned* selected, unsigned* refined);
+/* The per-target statistic the last force evaluation wrote beside the accelerations, double[shard_len]:
+ *   mixed mode:                  Q_i = sum over the source tiles of |tile partial sum|^2 (what the selection rule thresholds);
+ *   variant "strict_f64_t4_mag": S_i = sum_j |a_ij|, the sum of the pair terms' magnitudes (the yardstick of a cancelling
+ *                                sum's error: backward error = |da_i| / S_i, condition number kappa_i = S_i / |a_i|).
+ * NBX_ERR_STATE after any other evaluation.  Synchronises the stream. */
+int nbx_ctx_get_aux(nbx_ctx* ctx, double* out);
 /* The variant and slice count the next force evaluation will use (after upload). */
 int nbx_ctx_effective_tuning(nbx_ctx* ctx, int* variant, int* source_splits);
 int nbx_num_variants(void);
@@ -262,6 +286,7 @@ int nbx_node_verify_exchange(nbx_node* node, size_t* mismatches);
 int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
 int nbx_node_set_softening(nbx_node* node, double epsilon);   /* nbx_ctx_set_softening on every rank */
 int nbx_node_set_law(nbx_node* node, int law);                /* nbx_ctx_set_law on every rank */
+int nbx_node_set_refine(nbx_node* node, double rel_tolerance, double sigma_factor);   /* nbx_ctx_set_refine on every rank */
 /* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
 /* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */

@@ -57,6 +57,9 @@ ABI = [
     ("nbx_ctx_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_ctx_set_softening", _i, [_vp, _d]),
     ("nbx_ctx_set_law", _i, [_vp, _i]),
+    ("nbx_ctx_set_refine", _i, [_vp, _d, _d]),
+    ("nbx_ctx_refine_stats", _i, [_vp, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
+    ("nbx_ctx_get_aux", _i, [_vp, _vp]),
     ("nbx_ctx_close_set_mode", _i, [_vp, _pi, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
     ("nbx_ctx_effective_tuning", _i, [_vp, _pi, _pi]),
     ("nbx_num_variants", _i, []),
@@ -71,6 +74,7 @@ ABI = [
     ("nbx_node_set_tuning", _i, [_vp, _i, _i]),
     ("nbx_node_set_softening", _i, [_vp, _d]),
     ("nbx_node_set_law", _i, [_vp, _i]),
+    ("nbx_node_set_refine", _i, [_vp, _d, _d]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
     ("nbx_node_step_kdk", _i, [_vp, _d, _d, _i]),
@@ -257,6 +261,23 @@ class Context:
         """Extension: FORCE_LAW_REFERENCE (default) or FORCE_LAW_NEWTON (attractive, softened; needs set_softening > 0)."""
         self._ck(self.lib.nbx_ctx_set_law(self.h, int(law)), "nbx_ctx_set_law")
 
+    def set_refine(self, rel_tolerance: float, sigma_factor: float = 0.0):
+        """Mixed mode: fp32 for all targets, the strict fp64 kernel for those whose fp32 sum cannot be trusted to
+        rel_tolerance (0 switches it off); see nbx_ctx_set_refine in include/nbody_hip.h."""
+        self._ck(self.lib.nbx_ctx_set_refine(self.h, float(rel_tolerance), float(sigma_factor)), "nbx_ctx_set_refine")
+
+    def refine_stats(self) -> Tuple[int, int]:
+        """(selected, refined) of the last mixed-mode evaluation."""
+        a, b = ctypes.c_uint(0), ctypes.c_uint(0)
+        self._ck(self.lib.nbx_ctx_refine_stats(self.h, ctypes.byref(a), ctypes.byref(b)), "nbx_ctx_refine_stats")
+        return a.value, b.value
+
+    def aux(self) -> np.ndarray:
+        """Per-target statistic of the last evaluation: Q_i (mixed mode) or S_i = sum_j |a_ij| (strict_f64_t4_mag)."""
+        out = np.empty(self.count, dtype=np.float64)
+        self._ck(self.lib.nbx_ctx_get_aux(self.h, out.ctypes.data), "nbx_ctx_get_aux")
+        return out
+
     def effective_tuning(self) -> Tuple[str, int]:
         v, s = ctypes.c_int(0), ctypes.c_int(0)
         self._ck(self.lib.nbx_ctx_effective_tuning(self.h, ctypes.byref(v), ctypes.byref(s)), "nbx_ctx_effective_tuning")
@@ -380,6 +401,9 @@ class Node:
 
     def set_law(self, law: int):
         self._ck(self.lib.nbx_node_set_law(self.h, int(law)), "nbx_node_set_law")
+
+    def set_refine(self, rel_tolerance: float, sigma_factor: float = 0.0):
+        self._ck(self.lib.nbx_node_set_refine(self.h, float(rel_tolerance), float(sigma_factor)), "nbx_node_set_refine")
 
     def forces(self, G: float = REFERENCE_G) -> np.ndarray:
         out = np.empty((self.n_total, self.dim), dtype=np.float64)

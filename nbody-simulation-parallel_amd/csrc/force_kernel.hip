@@ -263,6 +263,138 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
     for (int q = 0; q < TPL; ++q) store_result<D>(a, out, tgt0 + q * 256u, ox[q], oy[q], oz[q]);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Strict fp64 kernel: the reference's own arithmetic type (vector.h:9-12, methods.cpp:21-37 are fp64 throughout) on the
+// device's fp32-representable inputs.  Same tiling as the exact fp32 kernel -- 256 lanes, TPL targets per lane, source
+// tiles of 256 bodies staged in LDS as doubles {x,y},{z,m} (two ds_read_b128 broadcasts per source) -- with
+//   d = p_j - p_i (exact: both operands are fp32 values), r^2 by fma, the reference's skip rule compared in fp64
+//   (r^2 < 1e-10, methods.cpp:24), 1/r^2 = v_rcp_f64 + NR Newton steps (2: full double precision), w = m/r^4, 3 fma,
+// and ONE fp64 accumulator per target and component over the whole source slice (no fp32 anywhere after the loads).
+// LIST = 0: every target of the chunk; the slice's fp64 sum v leaves as TWO fp32 planes of acc, hi = (float)v and
+//           lo = (float)(v - hi) (planes 2*slice and 2*slice+1): the consumers already add the planes in fp64 in plane
+//           order (state_kernels.hip sum_partials), which puts v back together to 2^-48 -- no consumer knows about this kernel.
+// LIST = 1: the targets listed in strict_list[0 .. counters[3]) (the mixed mode's suspects, refine_select_kernel); one
+//           target per lane, workgroup (x, y) takes list blocks x, x + gridDim.x, ... against source slice y and writes
+//           strict_acc[y][k][slot] in fp64; refine_fold_kernel adds the slices and rewrites the targets' planes.
+// -------------------------------------------------------------------------------------------------
+template <int D, int NR, int MAG>
+__device__ __forceinline__ void interact64(double sx, double sy, double sz, double sm, double ix, double iy, double iz,
+                                           double& ax, double& ay, double& az, double& mag) {
+    const double dx = sx - ix, dy = sy - iy;
+    double r2 = dx * dx;
+    r2 = __builtin_fma(dy, dy, r2);
+    double dz = 0.0;
+    if (D == 3) {
+        dz = sz - iz;
+        r2 = __builtin_fma(dz, dz, r2);
+    }
+    double w = __builtin_amdgcn_rcp(r2);   // v_rcp_f64: a seed, refined below
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+        const double e = __builtin_fma(-r2, w, 1.0);
+        w = __builtin_fma(w, e, w);
+    }
+    double s = (w * w) * sm;               // m_j / r^4
+    s = (r2 < kR2Skip64) ? 0.0 : s;        // methods.cpp:24; also discards the NaN of r2 = 0 (rcp = inf, 0 * inf)
+    ax = __builtin_fma(s, dx, ax);
+    ay = __builtin_fma(s, dy, ay);
+    if (D == 3) az = __builtin_fma(s, dz, az);
+    // |a_ij| = (m/r^4) r: the magnitude sums that backward errors are measured against need no more than fp32's sqrt
+    if (MAG) mag = __builtin_fma(s, (double)__builtin_sqrtf((float)r2), mag);
+}
+
+struct Tile64 { double2 xy, zm; };
+
+template <int D>
+__device__ __forceinline__ void stage64(Tile64& dst, const float4 v) {
+    dst.xy = double2{(double)v.x, (double)v.y};
+    dst.zm = double2{(double)v.z, (double)v.w};
+}
+
+__device__ __forceinline__ void store_hi_lo(const KArgs& a, float* __restrict__ hi_plane, float* __restrict__ lo_plane,
+                                            size_t idx, double v) {
+    if (a.accumulate) v += (double)hi_plane[idx] + (double)lo_plane[idx];
+    const float hi = (float)v;
+    hi_plane[idx] = hi;
+    lo_plane[idx] = (float)(v - (double)hi);
+}
+
+// MAG = 1 (diagnostic build): also S_i = sum_j |a_ij|, the sum of the pair terms' magnitudes, into aux[slice][i] -- what the
+// relative error of a cancelling sum is measured against (tests: backward error of the fp32 path for EVERY body).
+template <int D, int TPL, int WAVES, int UNROLL, int NR, int LIST, int MAG = 0>
+__global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
+    static_assert(!LIST || TPL == 1, "listed targets: one per lane");
+    static_assert(!(LIST && MAG), "magnitude sums: whole-chunk launches only");
+    __shared__ Tile64 tile[2][kTile];
+    const unsigned tid = threadIdx.x;
+    unsigned bx, by;
+    if (LIST) { bx = blockIdx.x; by = blockIdx.y; } else xcd_tile(bx, by);
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+    const unsigned n_list = LIST ? a.counters[3] : 0u;
+    const unsigned n_listed = n_list < a.strict_cap ? n_list : a.strict_cap;
+    const unsigned nblk = LIST ? (n_listed + 255u) / 256u : bx + 1u;
+
+    for (unsigned tb = bx; tb < nblk; tb += LIST ? gridDim.x : nblk) {
+        unsigned idx[TPL];
+        double ix[TPL], iy[TPL], iz[TPL], ox[TPL], oy[TPL], oz[TPL], om[MAG ? TPL : 1];
+        const unsigned slot = tb * 256u + tid;
+        const bool valid = !LIST || slot < n_listed;
+#pragma unroll
+        for (int q = 0; q < TPL; ++q) {
+            idx[q] = LIST ? a.strict_list[valid ? slot : 0] : tb * (256u * TPL) + q * 256u + tid;
+            ix[q] = (double)tp[idx[q]];
+            iy[q] = (double)tp[(size_t)a.pad + idx[q]];
+            iz[q] = (D == 3) ? (double)tp[2 * (size_t)a.pad + idx[q]] : 0.0;
+            ox[q] = oy[q] = oz[q] = 0.0;
+            if (MAG) om[q] = 0.0;
+        }
+        unsigned t = by * a.tiles_per_split;
+        unsigned t_end = t + a.tiles_per_split;
+        if (t_end > a.total_tiles) t_end = a.total_tiles;
+        TileWalk w;
+        w.seek(t, a.tiles_per_chunk);
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < t_end) nxt = load_source<D>(a, w, tid);
+        int buf = 0;
+        for (; t < t_end; ++t) {
+            stage64<D>(tile[buf][tid], nxt);
+            __syncthreads();
+            if (t + 1 < t_end) {
+                w.next(a.tiles_per_chunk);
+                nxt = load_source<D>(a, w, tid);
+            }
+            const Tile64* __restrict__ cur = tile[buf];
+#pragma unroll UNROLL
+            for (int j = 0; j < kTile; ++j) {
+                const double2 sxy = cur[j].xy, szm = cur[j].zm;   // same address in every lane: two ds_read_b128 broadcasts
+#pragma unroll
+                for (int q = 0; q < TPL; ++q)
+                    interact64<D, NR, MAG>(sxy.x, sxy.y, szm.x, szm.y, ix[q], iy[q], iz[q], ox[q], oy[q], oz[q], om[MAG ? q : 0]);
+            }
+            buf ^= 1;
+        }
+        if (LIST) {
+            if (valid) {
+                double* __restrict__ o = a.strict_acc + (size_t)by * D * a.strict_cap;
+                o[slot] = ox[0];
+                o[(size_t)a.strict_cap + slot] = oy[0];
+                if (D == 3) o[2 * (size_t)a.strict_cap + slot] = oz[0];
+            }
+            __syncthreads();   // the next list block reuses the tile buffers
+        } else {
+            float* __restrict__ hi = a.acc + (size_t)(2u * by) * D * a.pad;
+            float* __restrict__ lo = hi + (size_t)D * a.pad;
+#pragma unroll
+            for (int q = 0; q < TPL; ++q) {
+                store_hi_lo(a, hi, lo, idx[q], ox[q]);
+                store_hi_lo(a, hi, lo, (size_t)a.pad + idx[q], oy[q]);
+                if (D == 3) store_hi_lo(a, hi, lo, 2 * (size_t)a.pad + idx[q], oz[q]);
+                if (MAG) { float* __restrict__ mo = a.qsum + (size_t)by * a.pad + idx[q]; *mo = a.accumulate ? *mo + (float)om[q] : (float)om[q]; }
+            }
+        }
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2][kTile], unsigned bx, unsigned by);
 
@@ -277,7 +409,10 @@ __device__ __forceinline__ void close_set_path(const KArgs& a, float4 (&tile)[2]
 // and there is no close set: close_blocks = 0, bad_flag is not read.
 // SOFT = 2: softened NEWTONIAN law  a_i = sum_j m_j d / (r^2 + eps^2)^(3/2)  (nbx_ctx_set_law; the `--law newton` of
 // SURVEY 5/7; attractive -- the sign is applied with G by the consumers).  Never combined with ONE_RCP.
-template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0, int HI_SEL = 1, int XCD_MAP = 1>
+// QS = 1 (mixed mode, nbx_ctx_set_refine): the kernel also adds up, per target, |tile partial sum|^2 over the slice's tiles
+// (3 v_pk_fma_f32 per target pair and TILE, 0.1 % of the pair loop) and writes it to qsum[slice][i]: the spread that the
+// rounding error of this target's fp32 sum scales with (refine_select_kernel).
+template <int D, int PAIRS, int WAVES, int UNROLL, int ONE_RCP, int SOFT = 0, int HI_SEL = 1, int XCD_MAP = 1, int QS = 0>
 __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     __shared__ float4 tile[2][kTile];
@@ -292,7 +427,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
     const unsigned tgt0 = (bx - a.close_blocks) * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
-    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], ox[PAIRS], oy[PAIRS], oz[PAIRS];
+    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], ox[PAIRS], oy[PAIRS], oz[PAIRS], qq[QS ? PAIRS : 1];
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
         const unsigned i0 = tgt0 + (2 * q) * 256u, i1 = i0 + 256u;
@@ -300,6 +435,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
         iy[q] = f2{tp[(size_t)a.pad + i0], tp[(size_t)a.pad + i1]};
         iz[q] = (D == 3) ? f2{tp[2 * (size_t)a.pad + i0], tp[2 * (size_t)a.pad + i1]} : f2{0.f, 0.f};
         ox[q] = oy[q] = oz[q] = f2{0.f, 0.f};
+        if (QS) qq[q] = f2{0.f, 0.f};
     }
 
     unsigned t = by * a.tiles_per_split;
@@ -329,17 +465,28 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; oz[q] += az[q]; }
+        if (QS) {
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                qq[q] = __builtin_elementwise_fma(ax[q], ax[q], qq[q]);
+                qq[q] = __builtin_elementwise_fma(ay[q], ay[q], qq[q]);
+                if (D == 3) qq[q] = __builtin_elementwise_fma(az[q], az[q], qq[q]);
+            }
+        }
         buf ^= 1;
     }
 
     float* __restrict__ out = a.acc + (size_t)by * D * a.pad;
+    float* __restrict__ qout = QS ? a.qsum + (size_t)by * a.pad : nullptr;
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned i = tgt0 + (2 * q + h) * 256u;
-            if (SOFT || !a.bad_flag[i])  // flagged targets belong to close_set_path + scatter_close_kernel
+            if (SOFT || !a.bad_flag[i]) {  // flagged targets belong to close_set_path + scatter_close_kernel
                 store_result<D>(a, out, i, h ? ox[q].y : ox[q].x, h ? oy[q].y : oy[q].x, h ? oz[q].y : oz[q].x);
+                if (QS) { const float v = h ? qq[q].y : qq[q].x; qout[i] = a.accumulate ? qout[i] + v : v; }
+            }
         }
     }
 }
@@ -509,6 +656,61 @@ __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Mixed mode (nbx_ctx_set_refine): fp32 for every target, fp64 for the targets whose fp32 sum cannot be trusted to the
+// requested relative tolerance.  The rounding error of a target's fp32 sum does not scale with the sum but with what went
+// through the adders: with unit roundoff u, the 256-term tile sums and the <= 256 tile flushes contribute a variance of
+// about u^2/3 x sum over all running partial sums |p|^2, and the running sums inside a tile grow to the tile's own partial sum
+// a_tile -- so the error's standard deviation is  sigma_i ~ c u sqrt(Q_i),  Q_i = sum over tiles |a_tile|^2  (written by
+// the fast kernel's QS build at 3 packed fma per tile).  A target is a SUSPECT when tol |a_i| < k sigma_i, i.e.
+//     |a_i|^2 < c2 Q_i ,   c2 = (sigma_factor u / tol)^2        (sigma_factor = k c, calibrated on ALL bodies against the
+// strict kernel), which is a chance cancellation: the pulls of the tiles add up to far less than they
+// are.  Close-set targets (evaluated by the guarded side path, which keeps no Q) are always listed.  The list is rebuilt by
+// every force evaluation; its order depends on atomics, each target's result does not.
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void plane_sums(const KArgs& a, unsigned i, double (&v)[3], double& n2, double& Q) {
+    n2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        double t = 0.0;
+        for (int s = 0; s < a.splits; ++s) t += (double)a.acc[((size_t)s * D + k) * a.pad + i];
+        v[k] = t;
+        n2 += t * t;
+    }
+    Q = 0.0;
+    for (int s = 0; s < a.splits; ++s) Q += (double)a.qsum[(size_t)s * a.pad + i];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void refine_select_kernel(KArgs a) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.count) return;
+    double v[3], n2, Q;
+    plane_sums<D>(a, i, v, n2, Q);
+    const bool suspect = a.bad_flag[i] != 0u || !(Q * a.refine_c2 <= n2);   // a NaN anywhere lists the target
+    if (suspect) {
+        const unsigned slot = atomicAdd(&a.counters[3], 1u);
+        if (slot < a.strict_cap) a.strict_list[slot] = i;   // beyond the cap the fp32 result stands (counted, reported)
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void refine_fold_kernel(KArgs a) {
+    const unsigned n_list = a.counters[3];
+    const unsigned n = n_list < a.strict_cap ? n_list : a.strict_cap;
+    for (unsigned slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u) {
+        const unsigned i = a.strict_list[slot];
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int y = 0; y < a.strict_slices; ++y) v += a.strict_acc[((size_t)y * D + k) * a.strict_cap + slot];
+            const float hi = (float)v;
+            a.acc[(size_t)k * a.pad + i] = hi;
+            if (a.splits > 1) a.acc[((size_t)D + k) * a.pad + i] = (float)(v - (double)hi);
+            for (int s = 2; s < a.splits; ++s) a.acc[((size_t)s * D + k) * a.pad + i] = 0.0f;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Potential kernel (diagnostic for energy-drift checks, BASELINE config 5; SOFT = 1: sum_{j != i} m_j/(r^2+eps^2),
 // SOFT = 2: sum_{j != i} m_j/sqrt(r^2+eps^2) for the Newtonian law): phi_i = sum_j m_j / r_ij^2
 // over the selected sources with the reference's skip rule, so that the energy matching the reference
@@ -595,25 +797,34 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 }
 
 // ---- variant table: the default fast kernel, its one-reciprocal comparator, and the exact (guarded) kernel ------
-#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0, nullptr, nullptr, nullptr, nullptr
+#define NBX_LDS(TPL, WAVES, UNROLL) accel_lds_kernel<2, TPL, WAVES, UNROLL>, accel_lds_kernel<3, TPL, WAVES, UNROLL>, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0
+#define NBX_F64(TPL, WAVES, UNROLL, NR, MAG) accel_f64_kernel<2, TPL, WAVES, UNROLL, NR, 0, MAG>, accel_f64_kernel<3, TPL, WAVES, UNROLL, NR, 0, MAG>, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2, MAG
 #define NBX_FAST(PAIRS, WAVES, UNROLL, ONE_RCP) \
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP>, 1, 256, ONE_RCP, \
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 1>, \
-    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 0, 2>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 0, 2>
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 0, 2>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 0, 2>, \
+    accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, 1, 0
 
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
-    {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
+    {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},
     {"fastpk_t8_w3_u2", 8, NBX_FAST(4, 3, 2, 0)},
     {"fastpk_t8_w3_u8", 8, NBX_FAST(4, 3, 8, 0)},
     {"fastpk_t8_w2_u4", 8, NBX_FAST(4, 2, 4, 0)},
     {"fastpk_t4_w6_u4", 4, NBX_FAST(2, 6, 4, 0)},
     {"fastpk_t16_w1_u2", 16, NBX_FAST(8, 1, 2, 0)},
-    {"fastpk_t8_w3_u4_noxcd", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 1, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr},
+    {"fastpk_t8_w3_u4_noxcd", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 1, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},
 #endif
     {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
+    {"strict_f64_t4", 4, NBX_F64(4, 2, 2, 2, 0)},        // fp64 throughout (the reference's arithmetic type); ~2.5x the fast kernel's time
+    {"strict_f64_t4_mag", 4, NBX_F64(4, 2, 2, 2, 1)},    // + the magnitude sums S_i = sum_j |a_ij| (nbx_ctx_get_aux): the checker's build
+#ifdef NBX_AB_F64
+    {"strict_f64_t4_nr1", 4, NBX_F64(4, 2, 2, 1, 0)},
+    {"strict_f64_t2", 2, NBX_F64(2, 4, 4, 2, 0)},
+    {"strict_f64_t8", 8, NBX_F64(8, 1, 1, 2, 0)},
+#endif
 };
 
 }  // namespace
@@ -632,6 +843,9 @@ CloseKernels close_kernels() {
     k.potential[0] = potential_kernel<2, 0>;  k.potential[1] = potential_kernel<3, 0>;
     k.potential_soft[0] = potential_kernel<2, 1>; k.potential_soft[1] = potential_kernel<3, 1>;
     k.potential_newton[0] = potential_kernel<2, 2>; k.potential_newton[1] = potential_kernel<3, 2>;
+    k.refine_select[0] = refine_select_kernel<2>; k.refine_select[1] = refine_select_kernel<3>;
+    k.strict_list[0] = accel_f64_kernel<2, 1, 4, 4, 2, 1>; k.strict_list[1] = accel_f64_kernel<3, 1, 4, 4, 2, 1>;
+    k.refine_fold[0] = refine_fold_kernel<2>; k.refine_fold[1] = refine_fold_kernel<3>;
     return k;
 }
 

@@ -42,6 +42,10 @@ int variant_tpl(int v) { return valid(v) ? table().v[v].tpl : 1; }
 int variant_is_fast(int v) { return valid(v) ? table().v[v].fast : 0; }
 int variant_max_tiles_per_slice(int v) { return valid(v) ? table().v[v].max_tiles_per_slice : 0; }
 int variant_needs_extent(int v) { return valid(v) ? table().v[v].needs_extent : 0; }
+int variant_has_law_builds(int v) { return valid(v) && table().v[v].soft2 && table().v[v].soft3 && table().v[v].newton2 && table().v[v].newton3; }
+int variant_planes(int v) { return valid(v) ? table().v[v].planes : 1; }
+int variant_has_qsum(int v) { return valid(v) && table().v[v].qs2 && table().v[v].qs3; }
+int variant_writes_aux(int v) { return valid(v) ? table().v[v].aux : 0; }
 int default_fast_two_rcp_variant() { return table().def_two_rcp; }
 int variant_by_name(const char* name) {
     for (int i = 0; i < num_variants(); ++i)
@@ -65,12 +69,16 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.count = L.count;
     a.tiles_per_chunk = L.pad / kTile;
     a.total_tiles = (unsigned)L.vchunks * a.tiles_per_chunk;
-    a.tiles_per_split = (a.total_tiles + (unsigned)L.splits - 1) / (unsigned)L.splits;
+    if (L.splits % V.planes != 0) return hipErrorInvalidValue;   // acc planes = source slices x planes per slice
+    const unsigned slices = (unsigned)(L.splits / V.planes);
+    a.tiles_per_split = (a.total_tiles + slices - 1) / slices;
     a.tgt_chunk = L.tgt_chunk;
     a.chunk_first = L.chunk_first;
     a.chunk_skip = L.chunk_skip;
     a.accumulate = L.accumulate;
     a.splits = L.splits;
+    a.qsum = L.qsum;
+    a.strict_list = nullptr; a.strict_acc = nullptr; a.strict_cap = 0; a.strict_slices = 0; a.refine_c2 = 0.0;
     a.cand_list = L.cand_list;
     a.cand_pos = L.cand_pos;
     a.bad_list = L.bad_list;
@@ -85,6 +93,8 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     const bool soft = L.eps2 > 0.0f;
     if (soft && !(V.fast && V.soft2 && V.soft3)) return hipErrorInvalidValue;   // softened law: fast kernels only
     if (L.law != 0 && !(soft && V.newton2 && V.newton3)) return hipErrorInvalidValue;   // Newtonian law: softened only
+    if (L.qsum && !V.aux && (soft || !(V.qs2 && V.qs3))) return hipErrorInvalidValue;   // mixed mode: reference law, fast kernels
+    if (V.aux && !L.qsum) return hipErrorInvalidValue;
     // host-side shape checks: every target block and every source tile lies inside its chunk
     const unsigned tgt_per_block = 256u * (unsigned)V.tpl;
     if (L.pad % tgt_per_block != 0) return hipErrorInvalidValue;
@@ -131,15 +141,57 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
         }
     }
     if (L.lists_only) return hipSuccess;
-    dim3 grid(L.pad / tgt_per_block + a.close_blocks, (unsigned)L.splits, 1);
+    dim3 grid(L.pad / tgt_per_block + a.close_blocks, slices, 1);
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(L.law ? ((dim == 3) ? V.newton3 : V.newton2)
-                             : soft ? ((dim == 3) ? V.soft3 : V.soft2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
+                             : soft ? ((dim == 3) ? V.soft3 : V.soft2)
+                             : (L.qsum && !V.aux) ? ((dim == 3) ? V.qs3 : V.qs2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;
     if (!V.fast || soft) return hipSuccess;
     hipLaunchKernelGGL(table().ck.scatter[di], dim3(64, 1, 1), block, 0, stream, a);
+    return hipGetLastError();
+}
+
+namespace {
+// Kernel-side view of the refinement: the evaluation's planes and spread sums, and ALL chunks as the strict pass's sources.
+hipError_t refine_args(int dim, const RefineLaunch& R, KArgs& a) {
+    const AccelLaunch& L = R.base;
+    if ((dim != 2 && dim != 3) || L.pad == 0 || L.pad % kPadQuantum != 0 || L.splits < 1 || L.n_chunks < 1 || L.count > L.pad ||
+        !L.acc || !L.qsum || !L.counters || !L.bad_flag || R.grid_slices != L.splits)
+        return hipErrorInvalidValue;
+    a = KArgs{};
+    a.pos_all = L.pos_all; a.mass_all = L.mass_all; a.acc = L.acc; a.pad = L.pad; a.count = L.count;
+    a.tiles_per_chunk = L.pad / kTile;
+    a.total_tiles = (unsigned)L.n_chunks * a.tiles_per_chunk;
+    a.tgt_chunk = L.tgt_chunk; a.chunk_first = 0; a.chunk_skip = INT_MAX; a.accumulate = 0;
+    a.splits = L.splits;
+    a.bad_flag = L.bad_flag; a.counters = L.counters; a.qsum = L.qsum;
+    a.strict_list = R.strict_list; a.strict_acc = R.strict_acc; a.strict_cap = R.strict_cap; a.strict_slices = R.strict_slices;
+    a.refine_c2 = R.c2;
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
+    KArgs a;
+    hipError_t e = refine_args(dim, R, a);
+    if (e != hipSuccess) return e;
+    if (!R.strict_list || !R.strict_acc || R.strict_cap == 0 || R.strict_slices < 1 || (unsigned)R.strict_slices > a.total_tiles)
+        return hipErrorInvalidValue;
+    a.tiles_per_split = (a.total_tiles + (unsigned)R.strict_slices - 1) / (unsigned)R.strict_slices;
+    if (a.count == 0) return hipSuccess;
+    const int di = dim - 2;
+    const dim3 block(256, 1, 1);
+    if ((e = hipMemsetAsync(a.counters + 3, 0, sizeof(unsigned), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(table().ck.refine_select[di], dim3((a.count + 255u) / 256u, 1, 1), block, 0, stream, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // listed targets x strict slices; a workgroup whose list block does not exist returns at once
+    const unsigned list_blocks = (R.strict_cap + 255u) / 256u;
+    hipLaunchKernelGGL(table().ck.strict_list[di], dim3(list_blocks < 32u ? list_blocks : 32u, (unsigned)R.strict_slices, 1), block, 0, stream, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(table().ck.refine_fold[di], dim3(64, 1, 1), block, 0, stream, a);
     return hipGetLastError();
 }
 

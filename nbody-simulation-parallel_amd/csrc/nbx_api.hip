@@ -95,6 +95,12 @@ constexpr int kEventPairs = 512;
 constexpr int kMaxSplits = 256;
 constexpr int kPhiSlices = 16;
 constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from this many steps on
+// Mixed mode: selection rule |a|^2 < (sigma u / tol)^2 Q (force_kernel.hip).  The default sigma factor is calibrated on all
+// bodies of BASELINE's uniform 3D input at N = 2^20 and of config 5's Plummer sphere at N = 2^22 against the strict kernel
+// (profiles/r3/mixed_mode_calibration.txt).
+constexpr double kRefineSigmaDefault = 12.0;
+constexpr double kUnitRoundoffF32 = 0x1p-24;
+constexpr size_t kStrictAccBytesMax = (size_t)256 << 20;
 
 }  // namespace
 
@@ -153,13 +159,21 @@ int ensure_stage(nbx_ctx* c, size_t bytes) {
 int effective_variant(const nbx_ctx* c) {
     int v = c->variant_req >= 0 ? c->variant_req : default_variant();
     if (c->softening > 0.0) {  // softened law: the fast kernels with bias = eps^2; no close set, no guarded twin
-        if (!variant_is_fast(v)) v = default_variant();
+        if (!variant_is_fast(v) || !variant_has_law_builds(v)) v = default_variant();   // A/B table entries carry no soft build
         if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
         return v;
     }
     if (variant_is_fast(v) && c->force_exact) v = default_exact_variant();
     else if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
+    if (c->refine_tol > 0.0 && variant_is_fast(v) && !variant_has_qsum(v)) v = default_fast_two_rcp_variant();
     return v;
+}
+
+// Mixed mode runs when it is switched on, the law is the reference's and the kernel is a fast one (the guarded and the
+// strict kernels have nothing to refine: the first keeps fp64 second-level sums but fp32 terms -- it is a fallback, not a
+// precision mode -- the second is fp64 already).
+bool refine_active(const nbx_ctx* c, int variant) {
+    return c->refine_tol > 0.0 && !(c->softening > 0.0) && c->law == 0 && variant_is_fast(variant) && variant_has_qsum(variant);
 }
 
 // Source slices: enough workgroups that the launch is many "waves" of workgroups deep (a grid that just
@@ -186,14 +200,24 @@ int auto_splits(const nbx_ctx* c, int variant) {
     return (int)s;
 }
 
-int ensure_acc(nbx_ctx* c) {
-    c->variant = effective_variant(c);
-    if (!c->splits_user) c->splits = auto_splits(c, c->variant);
-    if (const int cap = variant_max_tiles_per_slice(c->variant)) {  // a caller's slice count is a lower bound
+// Source slices of the next launch of `variant`: the caller's count or the automatic one, raised to what the kernel's
+// fp32 second-level sums need, and such that slices x planes per slice stays within kMaxSplits planes.
+int slices_for(const nbx_ctx* c, int variant) {
+    int s = c->splits_user ? c->user_slices : auto_splits(c, variant);
+    if (const int cap = variant_max_tiles_per_slice(variant)) {  // a caller's slice count is a lower bound
         const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
         const int need = (int)((tiles + (unsigned)cap - 1) / (unsigned)cap);
-        if (c->splits < need) c->splits = need;
+        if (s < need) s = need;
     }
+    const int planes = variant_planes(variant);
+    if (s * planes > kMaxSplits) s = kMaxSplits / planes;
+    return s < 1 ? 1 : s;
+}
+
+int ensure_acc(nbx_ctx* c) {
+    c->variant = effective_variant(c);
+    const int slices = slices_for(c, c->variant);
+    c->splits = slices * variant_planes(c->variant);
     // Partial sums cost 12 B x slices x pad, and the slice count grows with the source count (<= 256 tiles per slice): a
     // single shard of more than ~16 M bodies would ask for > 50 GB here.  Say so instead of failing in hipMalloc.
     if ((size_t)c->splits * c->dim * c->pad * sizeof(float) > ((size_t)48 << 30))
@@ -232,7 +256,40 @@ int ensure_acc(nbx_ctx* c) {
             c->close_splits_alloc = c->splits;
         }
     }
+    if (refine_active(c, c->variant) || variant_writes_aux(c->variant)) {   // aux planes: one per source slice
+        if (!(c->qsum && c->qsum_slices_alloc >= c->splits)) {
+            if ((rc = dev_release(c, c->qsum, (size_t)c->qsum_slices_alloc * c->pad * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, &c->qsum, (size_t)c->splits * c->pad * sizeof(float)))) return rc;
+            c->qsum_slices_alloc = c->splits;
+        }
+        if (refine_active(c, c->variant) && !c->strict_list) {
+            // room for 1/16 of the shard (at least 4096 targets); the suspects are a fraction of a percent of uniform or
+            // Plummer bodies at the default rule.  As many strict slices as keep their fp64 partial sums within 256 MiB.
+            c->strict_cap = c->pad / 16 > 4096u ? c->pad / 16 : 4096u;
+            const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
+            size_t sl = kStrictAccBytesMax / ((size_t)c->dim * c->strict_cap * sizeof(double));
+            if (sl > 256) sl = 256;
+            if (sl > tiles) sl = tiles;
+            if (sl < 1) sl = 1;
+            c->strict_slices = (int)sl;
+            if ((rc = dev_alloc(c, &c->strict_list, (size_t)c->strict_cap * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->strict_acc, (size_t)c->strict_slices * c->dim * c->strict_cap * sizeof(double)))) return rc;
+        }
+    }
     return NBX_OK;
+}
+
+// The refinement of the evaluation that just finished (mixed mode): see RefineLaunch.
+RefineLaunch refine_launch(const nbx_ctx* c) {
+    RefineLaunch R = {};
+    R.base.pos_all = c->pos_all; R.base.mass_all = c->mass_all; R.base.acc = c->acc; R.base.pad = c->pad;
+    R.base.count = (unsigned)c->count; R.base.tgt_chunk = c->shard; R.base.splits = c->splits; R.base.n_chunks = c->n_shards;
+    R.base.counters = c->counters; R.base.bad_flag = c->bad_flag; R.base.qsum = c->qsum;
+    R.strict_list = c->strict_list; R.strict_acc = c->strict_acc; R.strict_cap = c->strict_cap; R.strict_slices = c->strict_slices;
+    const double r = (c->refine_sigma > 0.0 ? c->refine_sigma : kRefineSigmaDefault) * kUnitRoundoffF32 / c->refine_tol;
+    R.c2 = r * r;
+    R.grid_slices = c->splits;
+    return R;
 }
 
 constexpr int kPollEverySteps = 16;
@@ -548,7 +605,7 @@ int nbx_ctx_set_tuning(nbx_ctx* c, int source_splits, int variant) {
     if (source_splits < 0 || source_splits > kMaxSplits) return fail(NBX_ERR_INVALID, "source_splits must be in [0,256]");
     if (variant < -1 || variant >= num_variants()) return fail(NBX_ERR_INVALID, "unknown kernel variant");
     c->splits_user = source_splits > 0;
-    if (c->splits_user) c->splits = source_splits;
+    c->user_slices = source_splits;
     c->variant_req = variant;
     c->have_accel = false;
     return NBX_OK;
@@ -584,19 +641,51 @@ int nbx_ctx_set_law(nbx_ctx* c, int law) {
     return NBX_OK;
 }
 
+int nbx_ctx_set_refine(nbx_ctx* c, double rel_tolerance, double sigma_factor) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!(rel_tolerance == 0.0 || (rel_tolerance >= 1.0e-7 && rel_tolerance <= 1.0e-2)))
+        return fail(NBX_ERR_INVALID, "refine tolerance must be 0 (off) or in [1e-7, 1e-2]");
+    if (!(sigma_factor >= 0.0 && sigma_factor <= 1.0e6)) return fail(NBX_ERR_INVALID, "sigma factor must be 0 (default) or in (0, 1e6]");
+    c->refine_tol = rel_tolerance;
+    c->refine_sigma = sigma_factor;
+    c->have_accel = false;
+    return NBX_OK;
+}
+
+int nbx_ctx_refine_stats(nbx_ctx* c, unsigned* selected, unsigned* refined) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->have_accel || !refine_active(c, c->variant) || !c->qsum) return fail(NBX_ERR_STATE, "no mixed-mode evaluation on the device (nbx_ctx_set_refine, then compute)");
+    if (!c->refined) return fail(NBX_ERR_STATE, "the accelerations on the device are a LOCAL pass only");
+    int rc = set_device(c);
+    if (rc) return rc;
+    unsigned n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, c->counters + 3, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (selected) *selected = n;
+    if (refined) *refined = n < c->strict_cap ? n : c->strict_cap;
+    return NBX_OK;
+}
+
+int nbx_ctx_get_aux(nbx_ctx* c, double* out) {
+    if (!c || (!out && c->count)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!c->have_accel || !c->qsum || !(refine_active(c, c->variant) || variant_writes_aux(c->variant)))
+        return fail(NBX_ERR_STATE, "the last force evaluation wrote no per-target statistic (mixed mode or the strict_f64_t4_mag variant)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t bytes = c->count * sizeof(double);
+    rc = ensure_stage(c, bytes ? bytes : 8);
+    if (rc) return rc;
+    HIP_TRY(launch_export_aux(c->qsum, c->splits / variant_planes(c->variant), c->pad, c->count, c->stage, c->stream));
+    if (bytes) HIP_TRY(hipMemcpyAsync(out, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NBX_OK;
+}
+
 int nbx_ctx_effective_tuning(nbx_ctx* c, int* variant, int* source_splits) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
     const int v = effective_variant(c);
     if (variant) *variant = v;
-    if (source_splits) {
-        int s = c->splits_user ? c->splits : auto_splits(c, v);
-        if (const int cap = variant_max_tiles_per_slice(v)) {
-            const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
-            const int need = (int)((tiles + (unsigned)cap - 1) / (unsigned)cap);
-            if (s < need) s = need;
-        }
-        *source_splits = s;
-    }
+    if (source_splits) *source_splits = slices_for(c, v);
     return NBX_OK;
 }
 
@@ -619,6 +708,8 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.eps2 = (float)(c->softening * c->softening);
     L.law = c->law;
     L.lists_only = 0;
+    const bool refine = refine_active(c, c->variant);
+    L.qsum = (refine || variant_writes_aux(c->variant)) ? c->qsum : nullptr;
     if (c->hash_refine && variant_is_fast(c->variant) && !(c->softening > 0.0)) L.hash = c->hash;
     if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     if (c->softening > 0.0 && !(c->mass_max / ((double)L.eps2 * (double)L.eps2) < 1.0e38))
@@ -650,6 +741,13 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     if (timed) ++c->ev_used;
     ++c->launches_since_query;
     c->have_accel = true;
+    c->refined = false;
+    // mixed mode: once acc holds the sum over ALL sources (an ALL pass, or the REMOTE pass on top of LOCAL), the suspects
+    // are re-evaluated in fp64 against all chunks
+    if (refine && (which != NBX_SRC_LOCAL || c->n_shards == 1)) {
+        HIP_TRY(launch_refine(c->dim, refine_launch(c), c->stream));
+        c->refined = true;
+    }
     return NBX_OK;
 }
 
@@ -684,7 +782,8 @@ namespace {
 // about capture is unavailable; the caller then steps eagerly.
 bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
-        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law && c->graph_hash == c->hash_refine)
+        c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law && c->graph_hash == c->hash_refine &&
+        c->graph_refine_tol == c->refine_tol && c->graph_refine_sigma == c->refine_sigma)
         return true;
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -700,6 +799,7 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
     c->graph_eps = c->softening; c->graph_law = c->law; c->graph_hash = c->hash_refine;
+    c->graph_refine_tol = c->refine_tol; c->graph_refine_sigma = c->refine_sigma;
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }

@@ -11,8 +11,9 @@ struct nbx_ctx {
     int device = 0, dim = 3, n_shards = 1, shard = 0;
     size_t n_total = 0, shard_len = 0, count = 0;  // count = real bodies in this shard
     unsigned pad = 0;
-    int splits = 1, variant = 0;
+    int splits = 1, variant = 0;   // splits = fp32 planes of acc = source slices x planes per slice (2 for the strict kernel)
     bool splits_user = false;
+    int user_slices = 0;           // the caller's source_splits (nbx_ctx_set_tuning), a lower bound on the slice count
     bool uploaded = false, have_accel = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // exchange buffers (own or caller's)
@@ -42,10 +43,20 @@ struct nbx_ctx {
     bool counters_pending = false;
     int steps_since_poll = 0;
     unsigned last_cand = 0, last_bad = 0;   // most recent counts seen by the host
+    // mixed mode (nbx_ctx_set_refine): fp32 for all targets, the strict fp64 kernel for the suspects
+    double refine_tol = 0.0;         // requested relative tolerance (0: mixed mode off)
+    double refine_sigma = 0.0;       // sigma factor of the selection rule (force_kernel.hip refine_select_kernel)
+    float* qsum = nullptr;           // [slices][pad] spread sums written by the fast kernel's QS build
+    int qsum_slices_alloc = 0;
+    unsigned* strict_list = nullptr; // [strict_cap]
+    double* strict_acc = nullptr;    // [strict_slices][dim][strict_cap]
+    unsigned strict_cap = 0;
+    int strict_slices = 0;
+    bool refined = false;            // the accelerations on the device went through the refinement
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
     hipGraphExec_t step_exec = nullptr;
-    double graph_G = 0.0, graph_dt = 0.0, graph_eps = 0.0;
+    double graph_G = 0.0, graph_dt = 0.0, graph_eps = 0.0, graph_refine_tol = 0.0, graph_refine_sigma = 0.0;
     int graph_law = 0;
     bool graph_hash = false;
     int graph_variant = -1, graph_splits = 0;

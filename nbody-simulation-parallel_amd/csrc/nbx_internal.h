@@ -18,6 +18,7 @@ constexpr int kPadQuantum = 4096;
 // r2, (r2 < kR2SkipF) == ((double)r2 < 1e-10).   0x2edbe6ff = 1.00000001335e-10f.
 constexpr float kR2SkipF = 1.0e-10f;
 static_assert((double)kR2SkipF >= 1e-10, "fp32 threshold must not round below the fp64 one");
+constexpr double kR2Skip64 = 1.0e-10;   // the same threshold for the strict fp64 kernel, compared as the reference compares it
 
 // ---- close-pair bookkeeping of the fast force path (force_kernel.hip) --------------------------------
 // The fast kernel carries no per-pair guard: it biases r^2 by kTiny = 2^-47 so that coincident bodies
@@ -100,6 +101,9 @@ struct AccelLaunch {
     int law;                  // 0: the reference's r^-4 d law, 1: Newtonian r^-3 d (needs eps2 > 0)
     HashWork hash;            // non-null: refine through sorted cells instead of candidates x candidates
     int lists_only;           // 1: build the close-set lists and return (upload-time probe of the bad-target count)
+    // mixed mode (nbx_ctx_set_refine; see RefineLaunch): non-null = the fast kernel also writes, per slice and target, the sum
+    // over the slice's tiles of |tile partial sum|^2  -- [grid slices][pad]
+    float* qsum = nullptr;
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -128,6 +132,13 @@ struct KArgs {
     unsigned src_stride;       // floats between the coordinate planes of src_cand_pos (= n_chunks * pad)
     unsigned n_total, shard_len;
     float eps2;                // softened law: epsilon^2 (0: the reference law)
+    // mixed mode / strict kernel with listed targets
+    float* __restrict__ qsum;          // [grid slices][pad] or null
+    unsigned* __restrict__ strict_list;   // [strict_cap] targets to re-evaluate in fp64; their number is counters[3]
+    double* __restrict__ strict_acc;   // [strict slices][dim][strict_cap]
+    unsigned strict_cap;
+    int strict_slices;
+    double refine_c2;                  // a target is listed when |a|^2 < refine_c2 * Q  (Q = sum over slices of qsum)
 };
 
 struct KernelVariant {
@@ -142,10 +153,15 @@ struct KernelVariant {
     void (*soft3)(KArgs);
     void (*newton2)(KArgs);  // softened Newtonian law (two-reciprocal form of the same kernel)
     void (*newton3)(KArgs);
+    void (*qs2)(KArgs);      // the same fast kernel also writing KArgs::qsum (mixed mode; null: none)
+    void (*qs3)(KArgs);
+    int planes;              // fp32 planes of acc written per source slice: 1, or 2 = {hi, lo} of an fp64 sum (strict kernel)
+    int aux;                 // 1: the kernel itself writes KArgs::qsum (the strict kernel's magnitude-sum build)
 };
 // force_kernel.hip
 const KernelVariant* kernel_variants(int* count);
-struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); void (*potential_newton[2])(KArgs); };  // [0]: D=2, [1]: D=3
+struct CloseKernels { void (*classify[2])(KArgs); void (*classify_src[2])(KArgs); void (*refine[2])(KArgs); void (*scatter[2])(KArgs); void (*potential[2])(KArgs); void (*potential_soft[2])(KArgs); void (*potential_newton[2])(KArgs);
+                      void (*refine_select[2])(KArgs); void (*strict_list[2])(KArgs); void (*refine_fold[2])(KArgs); };  // [0]: D=2, [1]: D=3
 CloseKernels close_kernels();
 
 // close_hash.hip
@@ -154,6 +170,21 @@ hipError_t hash_refine(int dim, const KArgs& a, const HashWork& h, hipStream_t s
 
 // force_launch.hip
 hipError_t launch_accel(int dim, const AccelLaunch& a, hipStream_t stream);
+// Mixed mode, after the fast kernel has produced acc (all planes) and qsum (all slices) for the FULL source set:
+//   select: a target is a suspect when its acceleration is small against the spread of its tile partial sums,
+//           |a|^2 < c2 * sum_tiles |a_tile|^2 (or it is a close-set target) -> strict_list, count in counters[3];
+//   strict: accel_f64_kernel<LIST> over ALL chunks, the listed targets x strict_slices source slices, fp64 throughout;
+//   fold:   the slices added in fp64, the target's planes rewritten (plane 0 = hi, plane 1 = lo, the rest 0).
+struct RefineLaunch {
+    AccelLaunch base;          // pos/mass/acc/pad/count/tgt_chunk/n_chunks/counters/bad_flag/qsum of the evaluation to refine
+    unsigned* strict_list;
+    double* strict_acc;
+    unsigned strict_cap;
+    int strict_slices;
+    double c2;
+    int grid_slices;           // slices of the fast launch (planes of qsum)
+};
+hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream);
 // phi[splits][pad] = sum_j m_j / r^2 over ALL chunks (L.acc points at the phi buffer; L.splits slices)
 hipError_t launch_potential(int dim, const AccelLaunch& a, hipStream_t stream);
 int num_variants();
@@ -162,6 +193,10 @@ int variant_tpl(int variant);
 int variant_is_fast(int variant);
 int variant_max_tiles_per_slice(int variant);
 int variant_needs_extent(int variant);
+int variant_has_law_builds(int variant);  // softened / Newtonian builds of the kernel exist (the A/B table entries have none)
+int variant_planes(int variant);          // fp32 planes of acc per source slice (2: strict fp64 kernel)
+int variant_has_qsum(int variant);        // the variant has a build that writes qsum (mixed mode possible)
+int variant_writes_aux(int variant);      // the variant's own kernel writes qsum (strict magnitude-sum build)
 int default_fast_two_rcp_variant();   // fast variant without the extent precondition
 int variant_by_name(const char* name);
 int default_variant();        // the fast default
@@ -209,6 +244,8 @@ hipError_t launch_export_accel(const float* acc, int splits, int dim, unsigned p
 hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned pad, size_t count, double G,
                                 const double* v64, const double* m64, double* energy_out, hipStream_t stream);
 // *accurate = number of bodies whose force is within the reference's 1 % rule of ref_forces (device AoS double[count][dim])
+// out[count] (device, double) = sum over the aux planes of aux[plane][i], in plane order
+hipError_t launch_export_aux(const float* aux, int planes, unsigned pad, size_t count, double* out, hipStream_t stream);
 hipError_t launch_accuracy(const float* acc, int splits, int dim, unsigned pad, size_t count, double G,
                            const double* m64, const double* ref_forces, unsigned* accurate, hipStream_t stream);
 // state_out: AoS double[count][2*dim] = position then velocity

@@ -449,6 +449,15 @@ int nbx_node_set_law(nbx_node* nd, int law) {
     return NBX_OK;
 }
 
+int nbx_node_set_refine(nbx_node* nd, double rel_tolerance, double sigma_factor) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    for (Rank& k : nd->ranks) {
+        int rc = nbx_ctx_set_refine(k.ctx, rel_tolerance, sigma_factor);
+        if (rc) return rc;
+    }
+    return NBX_OK;
+}
+
 int nbx_node_compute_forces(nbx_node* nd, double G, double* forces_out) {
     if (!nd || (!forces_out && nd->n_total)) return fail(NBX_ERR_INVALID, "null argument");
     if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");

@@ -179,6 +179,15 @@ __global__ __launch_bounds__(256) void accuracy_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && votes) atomicAdd(accurate, (unsigned)__popcll(votes));
 }
 
+__global__ __launch_bounds__(256) void export_aux_kernel(const float* __restrict__ aux, int planes, unsigned pad, size_t count,
+                                                         double* __restrict__ out) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= count) return;
+    double v = 0.0;
+    for (int s = 0; s < planes; ++s) v += (double)aux[(size_t)s * pad + l];
+    out[l] = v;
+}
+
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -217,6 +226,12 @@ hipError_t launch_export_energy(const float* phi, int splits, int dim, unsigned 
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(energy_partials_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, phi, splits, dim, pad, count,
                        G, v64, m64, energy_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_aux(const float* aux, int planes, unsigned pad, size_t count, double* out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(export_aux_kernel, dim3(blocks_for(count)), dim3(256), 0, stream, aux, planes, pad, count, out);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_symbol(nbx):
     lib = ctypes.CDLL(nbx.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/nbody_hip.h but not exported"
-    assert nbx.load_library().nbx_abi_version() == 2
+    assert nbx.load_library().nbx_abi_version() == 3
 
 
 def test_header_cites_reference_interfaces():

@@ -1,0 +1,208 @@
+"""GPU: the strict fp64 kernel variant and the mixed mode (fp32 for all targets, fp64 for the suspects).
+
+The reference's arithmetic is fp64 throughout (nbody-sim-new/vector.h:9-12, methods.cpp:21-37); the strict kernel is that
+arithmetic type on the device's fp32-representable inputs, so against `brute_force_seq_n_body` on the same inputs it is held to
+    |dF_i| <= 1e-9 |F_i|   and   |dF_i| <= 2e-12 S_i      (S_i = sum_j |f_ij|; two fp64 summation orders)
+on small and edge-case inputs here and on >= 1,024 sampled rows at N = 2^20 / 2^22 in tests/all_bodies.py -- where, so pinned,
+it then checks EVERY body of the default fp32 path and of the mixed mode on the device."""
+import numpy as np
+import pytest
+
+import all_bodies
+from all_bodies import TOL_STRICT_BACKWARD, TOL_STRICT_REL
+from conftest import golden
+from oracle_lib import KAPPA_WELL, TOL_BACKWARD, TOL_REL
+
+pytestmark = pytest.mark.gpu
+STRICT = "strict_f64_t4"
+
+
+def _inputs(oracle, seed, n, dim):
+    return oracle.round_inputs_to_f32(oracle.generate(seed, n, dim))
+
+
+def _strict_forces(nbx, b, G, splits=0, variant=STRICT):
+    n, dim = b.shape[0], (b.shape[1] - 1) // 2
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_tuning(splits, nbx.variants().index(variant))
+        assert c.effective_tuning()[0] == variant
+        c.compute_accel()
+        return c.forces(G)
+
+
+def _assert_strict(f, ref, S, what):
+    d = np.sqrt(((f - ref) ** 2).sum(axis=1))
+    nrm = np.sqrt((ref ** 2).sum(axis=1))
+    assert np.isfinite(f).all(), what
+    assert (d <= TOL_STRICT_REL * nrm).all(), f"{what}: relative {np.max(d / np.where(nrm > 0, nrm, 1)):.3e}"
+    assert (d <= TOL_STRICT_BACKWARD * S).all(), f"{what}: backward {np.max(d / np.where(S > 0, S, 1)):.3e}"
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+@pytest.mark.parametrize("n", (1, 2, 3, 255, 257, 1024, 1025, 4096))
+def test_strict_matches_sequential_reference(nbx, oracle, dim, n):
+    b = _inputs(oracle, 100 + n, n, dim)
+    _assert_strict(_strict_forces(nbx, b, oracle.G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), f"D={dim} N={n}")
+
+
+@pytest.mark.parametrize("dim,n", [(d, n) for d in (2, 3) for n in (64, 1024)])
+def test_strict_on_the_golden_fixtures(nbx, oracle, dim, n):
+    """Outputs of the reference's own object code (tests/golden/make_golden.py)."""
+    g = golden(f"bf_D{dim}_N{n}.npz")
+    b = np.ascontiguousarray(g["bodies_f32"])
+    _assert_strict(_strict_forces(nbx, b, float(g["G"])), g["forces_seq_f32"], oracle.force_magnitude_sums(b), f"golden D={dim} N={n}")
+
+
+def test_strict_skip_rule_and_duplicates(nbx, oracle):
+    """methods.cpp:24 compared in fp64 on the device: r^2 = 9.8e-11 skipped, 1.21e-10 counted; coincident bodies contribute 0."""
+    k = golden("kat.npz")
+    G = oracle.G
+    f = _strict_forces(nbx, np.ascontiguousarray(k["two_bodies"]), G)
+    assert abs(f[0, 0] + G / 8) <= 1e-15 * G and abs(f[1, 0] - G / 8) <= 1e-15 * G and not f[:, 1:].any()
+    for name in ("near_skip", "near_keep"):
+        b = oracle.round_inputs_to_f32(np.ascontiguousarray(k[name + "_bodies"]))
+        ref = oracle.brute_force_seq(b)
+        got = _strict_forces(nbx, b, G)
+        if name == "near_skip":
+            assert not ref.any() and not got.any()
+        else:
+            assert ref[0, 0] < 0 and np.allclose(got, ref, rtol=1e-12, atol=0)
+    b = _inputs(oracle, 9, 600, 3)
+    b[100:110, :3] = b[5, :3]
+    b[300, :3] = (1.0, 1.0, 1.0)
+    b[301, :3] = (1.0 + 2.4e-7, 1.0, 1.0)
+    b = oracle.round_inputs_to_f32(b)
+    _assert_strict(_strict_forces(nbx, b, G), oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "duplicates")
+
+
+def test_strict_slices_and_shard_passes(nbx, oracle):
+    """hi/lo planes per source slice; LOCAL + REMOTE (accumulating into the planes) equal ALL to fp64 re-association."""
+    n, dim = 5000, 3
+    b = _inputs(oracle, 11, n, dim)
+    ref, S = oracle.brute_force_seq(b), oracle.force_magnitude_sums(b)
+    v = nbx.variants().index(STRICT)
+    for splits in (1, 2, 7):
+        _assert_strict(_strict_forces(nbx, b, oracle.G, splits), ref, S, f"splits={splits}")
+    for ranks in (2, 3):
+        for r in range(ranks):
+            with nbx.Context(n, dim, n_shards=ranks, shard=r) as c:
+                c.upload(b)
+                c.set_tuning(0, v)
+                c.compute_accel(nbx.SRC_LOCAL)
+                c.compute_accel(nbx.SRC_REMOTE)
+                lo = r * c.shard_len
+                _assert_strict(c.forces(oracle.G), ref[lo:lo + c.count], S[lo:lo + c.count], f"rank {r} of {ranks}")
+
+
+def test_strict_leapfrog_matches_the_oracle_trajectory(nbx, oracle):
+    """kick/drift fed by the strict kernel: a coupling strong enough to bend the paths, oracle leapfrog (methods.cpp:425-450)."""
+    n, dim, G, dt = 512, 3, oracle.G * 1e24, 0.25
+    b = _inputs(oracle, 21, n, dim)
+    ref = b.copy()
+    for _ in range(3):
+        f = oracle.brute_force_seq(ref) * (G / oracle.G)
+        oracle.update_body_velocities(ref, f, dt)
+        oracle.update_body_positions(ref, dt)
+    got = b.copy()
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_tuning(0, nbx.variants().index(STRICT))
+        for _ in range(3):   # positions are re-rounded to fp32 for the next force evaluation (the exchange buffer), like every variant
+            c.compute_accel()
+            c.kick_drift(dt, G)
+        c.download(got)
+    assert np.abs(got[:, dim:2 * dim] - b[:, dim:2 * dim]).max() > 1e-3, "the coupling must matter"
+    assert np.allclose(got[:, :2 * dim], ref[:, :2 * dim], rtol=2e-6, atol=0)
+
+
+def test_mixed_mode_small_systems(nbx, oracle):
+    """Mixed mode on small inputs: never worse than the plain fp32 path, the suspects come back at fp64 quality, and a
+    tolerance so tight that every target is a suspect reproduces the strict kernel."""
+    for dim, n in ((3, 3000), (2, 2500), (3, 100)):
+        b = _inputs(oracle, 33 + n, n, dim)
+        ref, S = oracle.brute_force_seq(b), oracle.force_magnitude_sums(b)
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.compute_accel()
+            plain = c.forces(oracle.G)
+            c.set_refine(1e-5)
+            c.compute_accel()
+            mixed = c.forces(oracle.G)
+            sel, done = c.refine_stats()
+            Q = c.aux()
+            assert sel == done and (Q >= 0).all()
+            e_plain = np.sqrt(((plain - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
+            e_mixed = np.sqrt(((mixed - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
+            changed = (mixed != plain).any(axis=1)
+            assert changed.sum() <= sel, "only listed targets may change"
+            assert (e_mixed[changed] <= 1e-7).all(), "re-evaluated targets come back in fp64 (rounded to the hi/lo planes)"
+            assert e_mixed.max() <= max(e_plain.max(), 1e-7)
+            c.set_refine(1e-7, 1e6)   # every target is a suspect: capacity is 4096 >= n here
+            c.compute_accel()
+            sel, done = c.refine_stats()
+            assert sel == n and done == n
+            _assert_strict(c.forces(oracle.G), ref, S, f"all targets refined D={dim} N={n}")
+            c.set_refine(0.0)
+            c.compute_accel()
+            assert np.array_equal(c.forces(oracle.G), plain), "switching the mode off restores the plain path bit for bit"
+
+
+def test_mixed_mode_sharded_and_stepping(nbx, oracle):
+    """The refinement runs after the REMOTE pass over ALL chunks, and inside graph-replayed steps."""
+    n, dim = 6000, 3
+    b = _inputs(oracle, 77, n, dim)
+    ref, S = oracle.brute_force_seq(b), oracle.force_magnitude_sums(b)
+    for r in range(3):
+        with nbx.Context(n, dim, n_shards=3, shard=r) as c:
+            c.upload(b)
+            c.set_refine(1e-7, 1e6)
+            c.compute_accel(nbx.SRC_LOCAL)
+            c.compute_accel(nbx.SRC_REMOTE)
+            lo = r * c.shard_len
+            assert c.refine_stats() == (c.count, c.count)
+            _assert_strict(c.forces(oracle.G), ref[lo:lo + c.count], S[lo:lo + c.count], f"mixed, rank {r} of 3")
+    G, dt = oracle.G * 1e24, 0.25
+    a, bb = b.copy(), b.copy()
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_refine(1e-5)
+        c.step(dt, 6, G)        # graph replay
+        c.download(a)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_refine(1e-5)
+        for _ in range(6):      # eager
+            c.compute_accel()
+            c.kick_drift(dt, G)
+        c.download(bb)
+    assert np.array_equal(a, bb), "graph-replayed mixed-mode steps equal eager ones bit for bit"
+
+
+def test_every_body_at_n1048576(nbx, oracle):
+    """BASELINE config 3's input: all 1,048,576 bodies of the default fp32 path and of the mixed mode against the strict kernel,
+    itself pinned to the oracle on >= 1,024 rows in the same test.  Frozen bounds (oracle_lib.py): T1 for every body, T2 for
+    kappa <= KAPPA_WELL, and the north star's plain 1e-5 for EVERY body in mixed mode."""
+    n = 1 << 20
+    b = _inputs(oracle, 3, n, 3)
+    rec = all_bodies.survey(nbx, oracle, b, "uniform 3D N=2^20 (BASELINE config 3 input, seed 3)")
+    all_bodies.write_record(rec)
+    print("\n" + "\n".join(f"  {k}: {v}" for k, v in rec.items()))
+    assert rec["default"]["max_backward"] <= TOL_BACKWARD, rec["default"]
+    assert rec["default"]["max_rel_kappa_le_4"] <= TOL_REL and KAPPA_WELL == 4.0, rec["default"]
+    assert rec["mixed"]["max_rel"] <= TOL_REL and rec["mixed"]["n_over_tol"] == 0, rec["mixed"]
+    assert rec["mixed"]["refined"] == rec["mixed"]["selected"] <= n // 50, rec["mixed"]
+    assert rec["mixed"]["cost_ms"] <= 0.02 * rec["default_ms"], "mixed mode must stay within 2 % of the plain path"
+
+
+def test_every_body_of_config5_n4194304(nbx, oracle):
+    """BASELINE config 5's input (Plummer sphere, N = 4,194,304): the same check of every body."""
+    n = 1 << 22
+    b = oracle.round_inputs_to_f32(nbx.plummer_bodies(n, 3, seed=5, a=1.0e5, total_mass=1.0e12))
+    rec = all_bodies.survey(nbx, oracle, b, "Plummer N=2^22 (BASELINE config 5 input, seed 5)")
+    all_bodies.write_record(rec)
+    print("\n" + "\n".join(f"  {k}: {v}" for k, v in rec.items()))
+    assert rec["default"]["max_backward"] <= TOL_BACKWARD, rec["default"]
+    assert rec["default"]["max_rel_kappa_le_4"] <= TOL_REL, rec["default"]
+    assert rec["mixed"]["max_rel"] <= TOL_REL and rec["mixed"]["n_over_tol"] == 0, rec["mixed"]
+    assert rec["mixed"]["refined"] == rec["mixed"]["selected"] <= n // 50, rec["mixed"]
