@@ -5,7 +5,8 @@ PKG      := nbody-simulation-parallel_amd
 CSRC     := $(PKG)/csrc
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+# -fvisibility=hidden: the shared library exports the entry points of include/nbody_hip.h and nothing else
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Iinclude
 LIB      := $(PKG)/libnbody_hip.so
 
 # host side: the reference's own flags (nbody-sim-new/Makefile:1-3)
@@ -47,8 +48,8 @@ $(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h
 $(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl
+$(LIB): $(OBJS) $(CSRC)/libnbody_hip.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl -Wl,--version-script=$(CSRC)/libnbody_hip.map
 
 oracle:
 	$(MAKE) -C oracle

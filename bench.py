@@ -126,32 +126,111 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
                       f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}", "host": host}
 
 
-def accuracy_check(system, bodies, G, nrows=1024):
-    """BASELINE metric, second half (SURVEY 8d protocol: >= 1,024 sampled target rows at N >= 2^20, all rows below):
-    max-abs / max-relative acceleration error of the device path against the reference's arithmetic (oracle rows in
-    fp64 on the fp32-representable inputs).  max_rel_accel_err is the PLAIN maximum over all compared bodies."""
+def _norm(a):
     import numpy as np
+    return np.sqrt((a * a).sum(axis=1))
+
+
+def parity_block(system, bodies, G, args, world, rank, dist, refine_tol=1.0e-5):
+    """BASELINE metric, second half, for ANY number of ranks -- run by every rank after the timed region.
+    (1) SURVEY 8d protocol: >= 1,024 sampled target rows (all rows at N <= 65,536) of one sharded force evaluation on the
+        initial positions, gathered to rank 0 and compared with the reference's arithmetic (oracle rows in fp64 on the
+        fp32-representable inputs): max-abs / max-relative acceleration error, backward error.
+    (2) EVERY body, on the device: the strict fp64 kernel variant (the reference's arithmetic type; pinned to the oracle on the
+        same sampled rows, here, first) is the yardstick for all N targets of the default fp32 path and of the mixed mode
+        (nbx_ctx_set_refine): each rank checks its own shard, rank 0 combines.
+    Returns the `accuracy` object on rank 0, None elsewhere."""
+    import numpy as np
+    import nbody_amd as nbx
+    be, ctx, lay = system.be, system.be.ctx, system.layout
+    n, dim = bodies.shape[0], args.dim
+    lo, hi = lay.bounds()
+    names = nbx.variants()
+    rows = np.arange(n) if n <= 65536 else np.unique(np.linspace(0, n - 1, 1024).astype(np.int64))
+    mine = rows[(rows >= lo) & (rows < hi)]
+    rounded_m = bodies[lo:hi, -1].astype(np.float32).astype(np.float64)
+
+    def evaluate():
+        be.synchronize()
+        ctx.upload(bodies)           # back to the initial state (the timed steps moved the bodies); every rank, all chunks
+        system.compute_forces()
+        return system.forces(G)
+
+    f_def = evaluate()
+    out = {"rank": rank, "lo": int(lo), "rows": mine, "f_rows": f_def[mine - lo]}
+    if not args.no_all_bodies and hi > lo:
+        ctx.set_tuning(args.splits, names.index("strict_f64_t4_mag"))
+        t0 = time.perf_counter()
+        f_str = evaluate()
+        be.synchronize()
+        out["strict_s"] = time.perf_counter() - t0
+        S = ctx.aux() * (abs(G) * rounded_m)
+        ctx.set_tuning(args.splits, args.variant)
+        ctx.set_refine(refine_tol)
+        f_mix = evaluate()
+        sel, done = ctx.refine_stats()
+        be.synchronize()
+        t0 = time.perf_counter()
+        system.step(args.dt, G, 3)      # what a mixed-mode step costs (not part of `value`)
+        be.synchronize()
+        out["mixed_step_s"] = (time.perf_counter() - t0) / 3
+        ctx.set_refine(0.0)
+        nrm = _norm(f_str)
+
+        def stats(f):
+            d = _norm(f - f_str)
+            rel, back = d / nrm, d / S
+            return {"max_rel": float(rel.max()), "n_over_1e-5": int((rel > 1e-5).sum()), "max_backward": float(back.max()),
+                    "rel_p99.9": float(np.percentile(rel, 99.9)), "rel_p50": float(np.percentile(rel, 50)),
+                    "kappa_at_max_rel": float((S / nrm)[int(np.argmax(rel))])}
+        out.update(strict_rows=f_str[mine - lo], S_rows=S[mine - lo], default=stats(f_def), mixed=stats(f_mix),
+                   selected=int(sel), refined=int(done), count=int(hi - lo))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+    else:
+        gathered = [out]
+    if rank != 0:
+        return None
     from oracle_lib import KAPPA_WELL, Oracle, force_errors
     o = Oracle()
-    n = bodies.shape[0]
-    system.be.ctx.upload(bodies)  # back to the initial state (the timed steps moved the bodies)
     rounded = o.round_inputs_to_f32(bodies)
-    rows = np.arange(n) if n <= 65536 else np.unique(np.linspace(0, n - 1, nrows).astype(np.int64))
-    ref = o.force_rows_omp_2(rounded, rows)
-    S = o.force_magnitude_sums(rounded, rows)
-    system.compute_forces()
-    f = system.forces(G)[rows]
+    ref = o.force_rows_omp_2(rounded, rows) * (G / o.G)
+    S_ref = o.force_magnitude_sums(rounded, rows) * (abs(G) / o.G)
+    got_rows = np.concatenate([g["rows"] for g in gathered])
+    assert np.array_equal(got_rows, rows), "the ranks' sampled rows must tile the sample"
+    f = np.concatenate([g["f_rows"] for g in gathered])
     m = rounded[rows, -1][:, None]
     da = (f - ref) / m
-    rel = np.sqrt((da ** 2).sum(1)) / np.sqrt(((ref / m) ** 2).sum(1))
-    e = force_errors(f, ref, S)
-    return {"rows": int(rows.size), "max_abs_accel_err": float(np.abs(da).max()), "max_rel_accel_err": float(rel.max()),
-            "within_1e-5_relative": bool(rel.max() <= 1e-5), "n_over_1e-5": int((rel > 1e-5).sum()),
-            "n_ill": e["n_ill"], "ill_means": f"kappa = sum_j|f_ij| / |F_i| > {KAPPA_WELL:g}",
-            "max_backward_err": e["max_backward"], "max_abs_accel": float(np.abs(ref / m).max()),
-            "reference": "oracle rows of brute_force_omp_n_body_2 in fp64 on the fp32-rounded inputs (= sequential path up to fp64 re-association)",
-            "all_bodies_note": "a sample: the one check of ALL 1,048,576 bodies of this configuration (profiles/r2/accuracy_full_n1048576.jsonl) "
-                               "found 39 bodies above 1e-5 relative, all ill-conditioned (kappa >= 11.5), worst 2.6e-5; max backward error 2.7e-6"}
+    rel = _norm(da) / _norm(ref / m)
+    e = force_errors(f, ref, S_ref)
+    acc = {"rows": int(rows.size), "ranks": world, "max_abs_accel_err": float(np.abs(da).max()), "max_rel_accel_err": float(rel.max()),
+           "within_1e-5_relative": bool(rel.max() <= 1e-5), "n_over_1e-5": int((rel > 1e-5).sum()),
+           "n_ill": e["n_ill"], "ill_means": f"kappa = sum_j|f_ij| / |F_i| > {KAPPA_WELL:g}",
+           "max_backward_err": e["max_backward"], "max_abs_accel": float(np.abs(ref / m).max()),
+           "reference": "oracle rows of brute_force_omp_n_body_2 in fp64 on the fp32-rounded inputs (= sequential path up to fp64 re-association)"}
+    parts = [g for g in gathered if "default" in g]
+    if parts:
+        fs = np.concatenate([g["strict_rows"] for g in gathered if "strict_rows" in g])
+        Ss = np.concatenate([g["S_rows"] for g in gathered if "S_rows" in g])
+        d = _norm(fs - ref)
+
+        def combine(key):
+            w = max(parts, key=lambda g: g[key]["max_rel"])[key]
+            return {"max_rel": w["max_rel"], "kappa_at_max_rel": w["kappa_at_max_rel"], "n_over_1e-5": sum(g[key]["n_over_1e-5"] for g in parts),
+                    "max_backward": max(g[key]["max_backward"] for g in parts), "rel_p99.9_worst_rank": max(g[key]["rel_p99.9"] for g in parts),
+                    "rel_p50_worst_rank": max(g[key]["rel_p50"] for g in parts)}
+        mixed = combine("mixed")
+        mixed.update(tolerance=refine_tol, selected=sum(g["selected"] for g in parts), refined=sum(g["refined"] for g in parts),
+                     ms_per_step=max(g["mixed_step_s"] for g in parts) * 1e3)
+        acc["all_bodies"] = {
+            "checked": sum(g["count"] for g in parts),
+            "yardstick": "strict fp64 kernel variant (strict_f64_t4_mag) on the device, every target x every source",
+            "yardstick_vs_oracle_rows": {"max_rel": float((d / _norm(ref)).max()), "max_backward": float((d / S_ref).max()),
+                                         "magnitude_sums_max_rel": float(np.abs(Ss / S_ref - 1.0).max())},
+            "strict_evaluation_s": max(g["strict_s"] for g in parts),
+            "default_fp32": combine("default"), "mixed_mode": mixed}
+    return acc
 
 
 def main():
@@ -165,6 +244,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--variant", type=int, default=-1, help="force-kernel variant id (-1: library default)")
     ap.add_argument("--splits", type=int, default=0, help="source slices (0: automatic)")
+    ap.add_argument("--refine", type=float, default=0.0, help="mixed mode for the TIMED steps: relative tolerance (0: off, the default)")
+    ap.add_argument("--no-all-bodies", action="store_true", help="skip the device-side check of every body against the strict fp64 kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -202,10 +283,12 @@ def main():
     if "NBODY_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["NBODY_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    check_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            check_group = dist.new_group(backend="gloo")   # the exchange self-check's bookkeeping rides a transport of its own
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -214,7 +297,8 @@ def main():
     N = args.bodies
 
     system = nbx.package.dist.make_hip_system(bodies, args.dim, rank=rank, world_size=world, device_index=local_rank,
-                                             variant=args.variant, source_splits=args.splits)
+                                             variant=args.variant, source_splits=args.splits, refine_tol=args.refine,
+                                             check_group=check_group)
     be = system.be
     G = nbx.REFERENCE_G
 
@@ -229,7 +313,11 @@ def main():
     # on the host with the generated bodies (identical on every rank).  A mismatch ends the run non-zero.
     exchange_check = None
     if world > 1:
-        bad = system.verify_exchange(bodies)
+        try:
+            bad = system.verify_exchange(bodies)
+        except nbx.package.dist.ExchangeError as e:
+            sys.stderr.write(f"[bench] rank {rank}: {e}\n")
+            os._exit(3)   # the communicator may be wedged: no collective teardown
         exchange_check = {"mismatching_values": bad, "checked_values_per_rank": int(args.dim * (N - system.layout.count)),
                           "transport": backend,
                           "all_gather_form": "in place" if getattr(be, "inplace_gather", True) else "separate send buffer (the in-place form failed its self-check)"}
@@ -337,10 +425,16 @@ def main():
         result["exchange_hidden_behind_local_pass"] = all(bool(r["exchange_hidden"]) for r in per_rank)
     if world > 1:
         dist.barrier()
+    if not args.no_cpu_baseline:   # parity of THIS run, whatever the rank count (every rank takes part; rank 0 holds the result)
+        acc = parity_block(system, bodies, G, args, world, rank, dist)
+        if rank == 0:
+            result["accuracy"] = acc
+            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)   # rank 0's host cores; the other ranks wait below
+    if world > 1:
+        dist.barrier()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result["accuracy"] = accuracy_check(system, bodies, G)   # on the initial positions: re-upload first
-            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)
+        if args.refine:
+            result["config"]["mixed_mode_tolerance"] = args.refine
         print(json.dumps(result), flush=True)
     be.close()
     if world > 1:

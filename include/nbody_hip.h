@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define NBX_ABI_VERSION 3   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only) */
 
@@ -206,7 +210,7 @@ int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
  *                              pair, or an exact variant selected)
  *   NBX_CLOSE_NONE             softened law: nothing to guard
  * Decided at upload and re-evaluated during long runs from an asynchronous read-back of the device counters every 16
- * steps (never a wait).  candidates_seen / bad_seen: the most recent counts the host has seen (0 before the first). */
+ * steps (never a wait) -- also inside one long nbx_ctx_step call, whose graph replays go out in blocks of 16 steps.  candidates_seen / bad_seen: the most recent counts the host has seen (0 before the first). */
 enum { NBX_CLOSE_CANDIDATE_PAIRS = 0, NBX_CLOSE_SORTED_CELLS = 1, NBX_CLOSE_GUARDED_KERNEL = 2, NBX_CLOSE_NONE = 3 };
 int nbx_ctx_close_set_mode(nbx_ctx* ctx, int* mode, unsigned* candidates_seen, unsigned* bad_seen);
 
@@ -214,8 +218,9 @@ int nbx_ctx_close_set_mode(nbx_ctx* ctx, int* mode, unsigned* candidates_seen, u
  *   a_i = sum_{j != i} m_j (p_j - p_i) / (r^2 + epsilon^2)^2 ,   U = sum_{i<j} G m_i m_j / (2 (r^2 + epsilon^2)),
  * every pair counted (no r^2 < 1e-10 skip; a body never acts on itself).  epsilon = 0 (default) is the reference law.
  * Same kernel, same speed: epsilon^2 replaces the fast kernel's r^2 bias and no close-set bookkeeping is needed.
- * epsilon must be 0 or in [1e-6, 1e15], and max|m| / epsilon^4 must be finite in fp32 (checked at the next force
- * evaluation).  Applies to compute_accel / step / energy of this context. */
+ * epsilon must be 0 or in [1e-6, 1e15], and max|m| / epsilon^4 (Newtonian law: / epsilon^3) must be a finite, normal fp32
+ * number -- neither overflow nor underflow to an all-zero field (checked at the next force evaluation: NBX_ERR_INVALID; with
+ * the reference's masses up to 1e8 that is epsilon <= ~3e9).  Applies to compute_accel / step / energy of this context. */
 int nbx_ctx_set_softening(nbx_ctx* ctx, double epsilon);
 /* EXTENSION (SURVEY 5/7 `--law {reference,newton}`; the reference has one law): NBX_FORCE_LAW_REFERENCE (default) is the
  * reference's repulsive m_j d / r^4 form; NBX_FORCE_LAW_NEWTON is the attractive, Plummer-softened Newtonian law
@@ -236,7 +241,7 @@ int nbx_ctx_set_law(nbx_ctx* ctx, int law);
  *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
  *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
  *    calibrated default.  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
- *    Newtonian law, or a non-fast variant.  At most 1/16 of a shard's targets (at least 4096) are re-evaluated per force
+ *    Newtonian law, or a non-fast variant.  At most 1/64 of a shard's targets (at least 16,384) are re-evaluated per force
  *    evaluation; nbx_ctx_refine_stats reports how many the rule selected and how many were re-evaluated. */
 int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);
 /* After a mixed-mode force evaluation: selected = targets the rule listed, refined = those re-evaluated in fp64
@@ -297,6 +302,9 @@ int nbx_node_download_bodies(nbx_node* node, void* bodies, size_t body_stride_by
 int nbx_node_energy(nbx_node* node, double G, double* kinetic, double* potential);
 int nbx_node_kernel_time(nbx_node* node, float* mean_ms, int* launches);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -98,7 +98,7 @@ constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from
 // Mixed mode: selection rule |a|^2 < (sigma u / tol)^2 Q (force_kernel.hip).  The default sigma factor is calibrated on all
 // bodies of BASELINE's uniform 3D input at N = 2^20 and of config 5's Plummer sphere at N = 2^22 against the strict kernel
 // (profiles/r3/mixed_mode_calibration.txt).
-constexpr double kRefineSigmaDefault = 12.0;
+constexpr double kRefineSigmaDefault = 48.0;
 constexpr double kUnitRoundoffF32 = 0x1p-24;
 constexpr size_t kStrictAccBytesMax = (size_t)256 << 20;
 
@@ -263,9 +263,11 @@ int ensure_acc(nbx_ctx* c) {
             c->qsum_slices_alloc = c->splits;
         }
         if (refine_active(c, c->variant) && !c->strict_list) {
-            // room for 1/16 of the shard (at least 4096 targets); the suspects are a fraction of a percent of uniform or
-            // Plummer bodies at the default rule.  As many strict slices as keep their fp64 partial sums within 256 MiB.
-            c->strict_cap = c->pad / 16 > 4096u ? c->pad / 16 : 4096u;
+            // room for 1/64 of the shard (at least 16,384 targets): the default rule lists 0.2-0.8 % of uniform or Plummer
+            // bodies.  As many strict slices (<= 256) as keep their fp64 partial sums within 256 MiB: a short list still
+            // spreads over the chip (one list block x 256 slices = 256 workgroups), a long one has the blocks for it.
+            c->strict_cap = c->pad / 64 > 16384u ? c->pad / 64 : 16384u;
+            if (c->strict_cap > c->pad) c->strict_cap = c->pad;
             const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
             size_t sl = kStrictAccBytesMax / ((size_t)c->dim * c->strict_cap * sizeof(double));
             if (sl > 256) sl = 256;
@@ -714,6 +716,11 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
     if (c->softening > 0.0 && !(c->mass_max / ((double)L.eps2 * (double)L.eps2) < 1.0e38))
         return fail(NBX_ERR_INVALID, "softening too small for these masses: m / eps^4 must stay finite in fp32");
+    // ... and too LARGE a softening length makes every pair weight underflow to zero in fp32 (the result would be an
+    // all-zero force field with status OK): the heaviest body's weight at zero distance must be a normal fp32 number
+    if (c->softening > 0.0 && c->mass_max > 0.0 &&
+        !(c->mass_max / (c->law ? (double)L.eps2 * c->softening : (double)L.eps2 * (double)L.eps2) > 1.0e-30))
+        return fail(NBX_ERR_INVALID, "softening too large for these masses: m / eps^4 (Newtonian law: m / eps^3) underflows in fp32");
     L.chunk_skip = INT_MAX; L.accumulate = 0;
     if (which == NBX_SRC_ALL) { L.chunk_first = 0; L.vchunks = c->n_shards; }
     else if (which == NBX_SRC_LOCAL) { L.chunk_first = c->shard; L.vchunks = 1; }
@@ -776,11 +783,10 @@ int nbx_ctx_kick_drift2(nbx_ctx* c, double G, double dt_kick, double dt_drift) {
 
 int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) { return nbx_ctx_kick_drift2(c, G, dt, dt); }
 
-namespace {
 // Capture one step on the context's stream into an executable graph (launch-bound regime: seven
 // launches per step cost ~7 % at N = 65,536).  Returns false -- leaving no capture open -- if anything
 // about capture is unavailable; the caller then steps eagerly.
-bool capture_step(nbx_ctx* c, double G, double dt) {
+static bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
         c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law && c->graph_hash == c->hash_refine &&
         c->graph_refine_tol == c->refine_tol && c->graph_refine_sigma == c->refine_sigma)
@@ -803,7 +809,6 @@ bool capture_step(nbx_ctx* c, double G, double dt) {
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }
-}  // namespace
 
 int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
@@ -825,13 +830,26 @@ int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
                 c->bulk_ms_done += ms; c->bulk_steps_done += c->bulk_steps; c->bulk_steps = 0;
             }
             HIP_TRY(hipEventRecord(c->bulk0, c->stream));
-            for (; s < nsteps; ++s) HIP_TRY(hipGraphLaunch(c->step_exec, c->stream));
+            // Replays go out in blocks of kPollEverySteps with a look at the close-set counters in between, so that one long
+            // call follows the bodies like a sequence of short ones does: when the host's view of the counters (an event
+            // query, never a wait) flips the refinement mode or demotes the kernel, the step is captured again.
+            bool replay = true;
+            while (s < nsteps && replay) {
+                const int block = nsteps - s < kPollEverySteps ? nsteps - s : kPollEverySteps;
+                for (int k = 0; k < block; ++k) HIP_TRY(hipGraphLaunch(c->step_exec, c->stream));
+                s += block;
+                c->have_accel = false;
+                c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+                rc = poll_close_counters(c, block);
+                if (rc) return rc;
+                if (s < nsteps && (c->graph_hash != c->hash_refine || c->graph_variant != effective_variant(c))) {
+                    rc = ensure_acc(c);
+                    if (rc) return rc;
+                    replay = capture_step(c, G, dt);   // false: the remaining steps run eagerly below
+                }
+            }
             HIP_TRY(hipEventRecord(c->bulk1, c->stream));
-            c->bulk_steps = nsteps;
-            c->have_accel = false;
-            c->tgt_cand_valid = 0; c->bad_list_pass = -1;
-            rc = poll_close_counters(c, nsteps);
-            if (rc) return rc;
+            c->bulk_steps = s;
         }
     }
     for (; s < nsteps; ++s) {

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs p) {
             }
             const double ax = fabs(x);
             cmin = (k == 0 || ax < cmin) ? ax : cmin;
-            cmax = !(ax <= cmax) ? ax : cmax;   // keeps a NaN
+            cmax = (cmax != cmax) ? cmax : (!(ax <= cmax) ? ax : cmax);   // sticky NaN: once seen, a later finite coordinate does not replace it
         }
         const double m = real ? src[2 * p.dim] : 0.0;
         p.mass_all[(size_t)g * p.pad + l] = (float)m;

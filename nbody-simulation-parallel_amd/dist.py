@@ -31,7 +31,7 @@ class HipShardBackend:
     """Shard compute on one MI355X: kernels via libnbody_hip.so, buffers and streams via torch."""
 
     def __init__(self, bodies: np.ndarray, layout: ShardLayout, device_index: int, variant: int = -1,
-                 source_splits: int = 0):
+                 source_splits: int = 0, refine_tol: float = 0.0):
         if not torch.cuda.is_available():
             raise capi.NbxError(capi.NBX_ERR_NO_DEVICE, "HipShardBackend", "no GPU visible to torch; there is no CPU fallback")
         self.layout = layout
@@ -47,6 +47,8 @@ class HipShardBackend:
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self.ctx.set_stream(self.compute_stream.cuda_stream)
         self.ctx.set_tuning(source_splits, variant)
+        if refine_tol:
+            self.ctx.set_refine(refine_tol)   # mixed mode: the suspects of every evaluation re-evaluated in fp64 after the REMOTE pass
         torch.cuda.synchronize(self.device)  # zero fills done before the library's stream writes
         self.ctx.upload(bodies)
         self._timing = False
@@ -197,13 +199,20 @@ def _count_chunk_mismatches(pos_all_host: np.ndarray, bodies: np.ndarray, layout
     return bad
 
 
-class ShardedNBody:
-    """The stepping loop of one rank.  `backend` supplies the shard compute (see module docstring)."""
+class ExchangeError(RuntimeError):
+    """The position exchange raised on at least one rank: the communicator may be wedged, nothing is retried."""
 
-    def __init__(self, backend, layout: ShardLayout, group=None):
+
+class ShardedNBody:
+    """The stepping loop of one rank.  `backend` supplies the shard compute (see module docstring).
+    check_group: process group for the self-check's bookkeeping reductions -- give it a transport independent of the one
+    under test (bench.py: a gloo group beside the RCCL one), so that a rank whose collective raised still meets the others."""
+
+    def __init__(self, backend, layout: ShardLayout, group=None, check_group=None):
         self.be = backend
         self.layout = layout
         self.group = group
+        self.check_group = check_group
         if layout.n_shards > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for n_shards > 1")
@@ -232,28 +241,35 @@ class ShardedNBody:
             return 0
         total = self._verify_once(bodies)
         if total and getattr(self.be, "inplace_gather", False):
-            # the in-place all-gather did not deliver (every rank sees the same total, so every rank takes this branch):
-            # one more try with a separate send buffer before giving up
+            # the in-place all-gather ran without raising anywhere but did not deliver (every rank sees the same total, so
+            # every rank takes this branch): one more try with a separate send buffer before giving up
             self.be.inplace_gather = False
             total = self._verify_once(bodies)
         return total
 
     def _verify_once(self, bodies: np.ndarray) -> int:
+        """One poisoned-buffer exchange.  Every rank runs the same sequence of collectives whatever happens locally: only the
+        exchange itself and the host compare sit inside the try; the outcome {mismatches, raised} is then summed over the ranks
+        on check_group.  If the exchange RAISED anywhere, ExchangeError on every rank -- no retry on a communicator that may be
+        wedged (ranks still inside a collective that others abandoned can only be released by the transport's own timeout)."""
         self.be.poison_remote_chunks()
-        failed = 0
+        bad, failed = 0, 0
         try:
             work = self.be.start_exchange(self.group)
             self.be.finish_exchange(work)
             bad = self.be.remote_chunk_mismatches(bodies)
-        except RuntimeError as e:            # a collective that raises counts as one that delivered nothing
+        except RuntimeError as e:
             import sys
             sys.stderr.write(f"[dist] rank {self.layout.shard}: position exchange raised: {e}\n")
-            bad, failed = 1, 1
-        t = torch.tensor([bad], dtype=torch.int64)
-        if dist.get_backend(self.group) == "nccl":
+            failed = 1
+        grp = self.check_group if self.check_group is not None else self.group
+        t = torch.tensor([bad, failed], dtype=torch.int64)
+        if dist.get_backend(grp) == "nccl":
             t = t.cuda()
-        dist.all_reduce(t, group=self.group)
-        return int(t.item())
+        dist.all_reduce(t, group=grp)
+        if int(t[1].item()):
+            raise ExchangeError(f"the position exchange raised on {int(t[1].item())} of {self.layout.n_shards} ranks")
+        return int(t[0].item())
 
     def step(self, dt: float, G: float = capi.REFERENCE_G, nsteps: int = 1):
         for _ in range(nsteps):
@@ -312,7 +328,7 @@ class ShardedNBody:
 
 
 def make_hip_system(bodies: np.ndarray, dim: int, rank: int = 0, world_size: int = 1, device_index: Optional[int] = None,
-                    group=None, variant: int = -1, source_splits: int = 0) -> ShardedNBody:
+                    group=None, variant: int = -1, source_splits: int = 0, refine_tol: float = 0.0, check_group=None) -> ShardedNBody:
     layout = ShardLayout(n_total=bodies.shape[0], n_shards=world_size, shard=rank, dim=dim)
-    be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits)
-    return ShardedNBody(be, layout, group)
+    be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits, refine_tol)
+    return ShardedNBody(be, layout, group, check_group)

@@ -31,6 +31,16 @@ def test_library_exports_every_symbol(nbx):
     assert nbx.load_library().nbx_abi_version() == 3
 
 
+def test_library_exports_nothing_but_the_header(nbx):
+    """The other direction: `nm -D --defined-only` of the shared library lists the header's entry points and nothing else
+    (built with -fvisibility=hidden and a linker version script, csrc/libnbody_hip.map) -- no mangled internals, no helper
+    that happens to sit in an extern "C" block."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", nbx.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()})
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_header_cites_reference_interfaces():
     txt = open(HEADER).read()
     for cite in ("methods.h:29-37", "methods.h:85-91", "methods.cpp:425-450", "body.h:8-11", "utils.h:87-104"):

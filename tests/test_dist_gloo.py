@@ -45,6 +45,25 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         broken = sysm.verify_exchange(bodies)
         be.start_exchange = real_start
         assert sysm.verify_exchange(bodies) == 0           # and the buffers are whole again
+        # a collective that RAISES on one rank only: every rank must still meet in the bookkeeping reduction (on a group of
+        # its own) and every rank must end with ExchangeError -- nobody retries on a communicator that may be wedged
+        raised = 0
+        if world > 1:
+            chk = dist.new_group(backend="gloo")
+            sysc = pkg.dist.ShardedNBody(be, layout, check_group=chk)
+            real_finish = be.finish_exchange
+
+            def finish_raising_on_rank0(work):
+                real_finish(work)
+                if rank == 0:
+                    raise RuntimeError("injected: the collective reported an error on this rank")
+            be.finish_exchange = finish_raising_on_rank0
+            try:
+                sysc.verify_exchange(bodies)
+            except pkg.dist.ExchangeError:
+                raised = 1
+            be.finish_exchange = real_finish
+            assert sysc.verify_exchange(bodies) == 0
         del be.calls[:]
         sysm.compute_forces()
         f0 = sysm.forces(o.G * gscale)
@@ -59,7 +78,7 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         final_kdk = sys2.gather_bodies(bodies)
         lo, hi = layout.bounds()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), f0=f0, final=final, lo=lo, hi=hi, calls=np.array(be.calls[:ncalls]),
-                 energy=np.array([ke, pe]), verify=np.array([clean, broken]), final_kdk=final_kdk)
+                 energy=np.array([ke, pe]), verify=np.array([clean, broken, raised]), final_kdk=final_kdk)
     finally:
         dist.destroy_process_group()
 
@@ -88,6 +107,7 @@ def test_sharded_steps_match_oracle(tmp_path, oracle, world, n, dim):
         finals.append(z["final"])
         others = n - (hi - lo)
         assert z["verify"][0] == 0 and (z["verify"][1] == dim * (world * n - n) if world > 1 else z["verify"][1] == 0), z["verify"]
+        assert z["verify"][2] == (1 if world > 1 else 0), "an exchange that raises on one rank must raise ExchangeError on every rank"
         calls = list(z["calls"])
         per = ["exchange", "local", "remote"] if world > 1 else ["exchange", "local"]
         assert calls == per + (per + ["kick_drift"]) * steps, "exchange must precede the local pass every step"
