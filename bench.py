@@ -148,11 +148,16 @@ def parity_block(system, bodies, G, args, world, rank, dist, refine_tol=1.0e-5):
     names = nbx.variants()
     rows = np.arange(n) if n <= 65536 else np.unique(np.linspace(0, n - 1, 1024).astype(np.int64))
     mine = rows[(rows >= lo) & (rows < hi)]
-    rounded_m = bodies[lo:hi, -1].astype(np.float32).astype(np.float64)
+    # the device rounds positions and masses to fp32 at the boundary; the checker's inputs ARE those values, so
+    # they are uploaded as such -- the fp64 mass that scales a force is then the mass the oracle uses
+    initial = bodies.copy()
+    initial[:, :dim] = initial[:, :dim].astype(np.float32).astype(np.float64)
+    initial[:, -1] = initial[:, -1].astype(np.float32).astype(np.float64)
+    rounded_m = initial[lo:hi, -1]
 
     def evaluate():
         be.synchronize()
-        ctx.upload(bodies)           # back to the initial state (the timed steps moved the bodies); every rank, all chunks
+        ctx.upload(initial)          # back to the initial state (the timed steps moved the bodies); every rank, all chunks
         system.compute_forces()
         return system.forces(G)
 
@@ -195,6 +200,7 @@ def parity_block(system, bodies, G, args, world, rank, dist, refine_tol=1.0e-5):
     from oracle_lib import KAPPA_WELL, Oracle, force_errors
     o = Oracle()
     rounded = o.round_inputs_to_f32(bodies)
+    assert np.array_equal(rounded[:, :dim], initial[:, :dim]) and np.array_equal(rounded[:, -1], initial[:, -1])
     ref = o.force_rows_omp_2(rounded, rows) * (G / o.G)
     S_ref = o.force_magnitude_sums(rounded, rows) * (abs(G) / o.G)
     got_rows = np.concatenate([g["rows"] for g in gathered])
@@ -283,14 +289,17 @@ def main():
     if "NBODY_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["NBODY_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    check_group = None
+    check_store = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            check_group = dist.new_group(backend="gloo")   # the exchange self-check's bookkeeping rides a transport of its own
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        try:   # the exchange self-check's bookkeeping rides the rendezvous store: a transport of its own, nothing printed
+            check_store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            check_store = None
 
     # synthetic bodies, identical on every rank (the reference generator's stream, seeded)
     bodies = nbx.uniform_bodies(args.bodies, args.dim, args.seed)
@@ -298,7 +307,7 @@ def main():
 
     system = nbx.package.dist.make_hip_system(bodies, args.dim, rank=rank, world_size=world, device_index=local_rank,
                                              variant=args.variant, source_splits=args.splits, refine_tol=args.refine,
-                                             check_group=check_group)
+                                             check_store=check_store)
     be = system.be
     G = nbx.REFERENCE_G
 

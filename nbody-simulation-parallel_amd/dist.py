@@ -205,14 +205,16 @@ class ExchangeError(RuntimeError):
 
 class ShardedNBody:
     """The stepping loop of one rank.  `backend` supplies the shard compute (see module docstring).
-    check_group: process group for the self-check's bookkeeping reductions -- give it a transport independent of the one
-    under test (bench.py: a gloo group beside the RCCL one), so that a rank whose collective raised still meets the others."""
+    check_store: a torch.distributed key-value store (bench.py: the rendezvous TCPStore) for the self-check's bookkeeping --
+    a transport independent of the collective under test, so that a rank whose collective raised still meets the others.
+    Without one the bookkeeping is an all_reduce on `group` itself."""
 
-    def __init__(self, backend, layout: ShardLayout, group=None, check_group=None):
+    def __init__(self, backend, layout: ShardLayout, group=None, check_store=None):
         self.be = backend
         self.layout = layout
         self.group = group
-        self.check_group = check_group
+        self.check_store = check_store
+        self._check_round = 0
         if layout.n_shards > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for n_shards > 1")
@@ -250,7 +252,7 @@ class ShardedNBody:
     def _verify_once(self, bodies: np.ndarray) -> int:
         """One poisoned-buffer exchange.  Every rank runs the same sequence of collectives whatever happens locally: only the
         exchange itself and the host compare sit inside the try; the outcome {mismatches, raised} is then summed over the ranks
-        on check_group.  If the exchange RAISED anywhere, ExchangeError on every rank -- no retry on a communicator that may be
+        through check_store (or `group`).  If the exchange RAISED anywhere, ExchangeError on every rank -- no retry on a communicator that may be
         wedged (ranks still inside a collective that others abandoned can only be released by the transport's own timeout)."""
         self.be.poison_remote_chunks()
         bad, failed = 0, 0
@@ -262,14 +264,25 @@ class ShardedNBody:
             import sys
             sys.stderr.write(f"[dist] rank {self.layout.shard}: position exchange raised: {e}\n")
             failed = 1
-        grp = self.check_group if self.check_group is not None else self.group
-        t = torch.tensor([bad, failed], dtype=torch.int64)
-        if dist.get_backend(grp) == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, group=grp)
-        if int(t[1].item()):
-            raise ExchangeError(f"the position exchange raised on {int(t[1].item())} of {self.layout.n_shards} ranks")
-        return int(t[0].item())
+        if self.check_store is not None:
+            # every rank posts its outcome under a key of this round and reads everybody's (get blocks until the key exists)
+            self._check_round += 1
+            base = f"nbx_exchange_check/{self._check_round}/"
+            self.check_store.set(base + str(self.layout.shard), f"{bad},{failed}")
+            total_bad = total_failed = 0
+            for g in range(self.layout.n_shards):
+                b, f = self.check_store.get(base + str(g)).decode().split(",")
+                total_bad += int(b)
+                total_failed += int(f)
+        else:
+            t = torch.tensor([bad, failed], dtype=torch.int64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            total_bad, total_failed = int(t[0].item()), int(t[1].item())
+        if total_failed:
+            raise ExchangeError(f"the position exchange raised on {total_failed} of {self.layout.n_shards} ranks")
+        return total_bad
 
     def step(self, dt: float, G: float = capi.REFERENCE_G, nsteps: int = 1):
         for _ in range(nsteps):
@@ -328,7 +341,7 @@ class ShardedNBody:
 
 
 def make_hip_system(bodies: np.ndarray, dim: int, rank: int = 0, world_size: int = 1, device_index: Optional[int] = None,
-                    group=None, variant: int = -1, source_splits: int = 0, refine_tol: float = 0.0, check_group=None) -> ShardedNBody:
+                    group=None, variant: int = -1, source_splits: int = 0, refine_tol: float = 0.0, check_store=None) -> ShardedNBody:
     layout = ShardLayout(n_total=bodies.shape[0], n_shards=world_size, shard=rank, dim=dim)
     be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits, refine_tol)
-    return ShardedNBody(be, layout, group, check_group)
+    return ShardedNBody(be, layout, group, check_store)

@@ -67,9 +67,63 @@ int timed(int variant, const double* raw, size_t n, double* seconds) {
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return got == n ? 0 : -2;
 }
+// The reference's BVH (bvh.h:77-103, bvh.cpp:16-126): built by its own constructor, its leaves read through the public
+// `root` in left-to-right order, a leaf's bodies as indices into the caller's array (the tree holds Body<D>* into the vector
+// it was built from, bvh.cpp:24-27).
+template <int D>
+void bvh_collect(const BVHNode<D>* node, std::vector<const BVHNode<D>*>& out) {
+    if (!node) return;
+    if (node->is_leaf) { out.push_back(node); return; }
+    bvh_collect<D>(node->left.get(), out);
+    bvh_collect<D>(node->right.get(), out);
+}
+template <int D>
+int bvh_leaves(const double* raw, size_t n, int max_bodies, uint32_t* leaf_offsets, uint32_t* leaf_bodies, size_t* n_leaves) {
+    auto b = wrap<D>(raw, n);
+    BVH<D> tree(b, max_bodies);
+    std::vector<const BVHNode<D>*> leaves;
+    bvh_collect<D>(tree.root.get(), leaves);
+    size_t k = 0;
+    leaf_offsets[0] = 0;
+    for (size_t l = 0; l < leaves.size(); ++l) {
+        for (const Body<D>* p : leaves[l]->bodies) leaf_bodies[k++] = (uint32_t)(p - b.data());
+        leaf_offsets[l + 1] = (uint32_t)k;
+    }
+    *n_leaves = leaves.size();
+    return k == n ? 0 : -2;
+}
+// For every body the sum over ALL leaves of BVH<D>::calculate_force(body, leaf) (bvh.cpp:143-176: the leaf branch, a direct
+// loop over the leaf's bodies): the near-field term of the BVH method with every leaf on every list, in the reference's own
+// arithmetic.  No internal node is ever passed, so the approximation branch (bvh.cpp:178-246) is not involved.
+template <int D>
+int bvh_leaf_forces(const double* raw, size_t n, int max_bodies, double* out) {
+    auto b = wrap<D>(raw, n);
+    BVH<D> tree(b, max_bodies);
+    std::vector<const BVHNode<D>*> leaves;
+    bvh_collect<D>(tree.root.get(), leaves);
+    std::vector<Vector<D>> f(n);
+    for (size_t i = 0; i < n; ++i) {
+        Vector<D> sum;
+        for (const BVHNode<D>* leaf : leaves) sum += tree.calculate_force(b[i], leaf);
+        f[i] = sum;
+    }
+    unwrap<D>(f, out);
+    return 0;
+}
 }  // namespace
 
 extern "C" {
+
+int ref_bvh_leaves(const double* bodies, size_t n, int D, int max_bodies, uint32_t* leaf_offsets, uint32_t* leaf_bodies, size_t* n_leaves) {
+    if (D == 2) return bvh_leaves<2>(bodies, n, max_bodies, leaf_offsets, leaf_bodies, n_leaves);
+    if (D == 3) return bvh_leaves<3>(bodies, n, max_bodies, leaf_offsets, leaf_bodies, n_leaves);
+    return -1;
+}
+int ref_bvh_leaf_forces(const double* bodies, size_t n, int D, int max_bodies, double* out) {
+    if (D == 2) return bvh_leaf_forces<2>(bodies, n, max_bodies, out);
+    if (D == 3) return bvh_leaf_forces<3>(bodies, n, max_bodies, out);
+    return -1;
+}
 
 int ref_sizeof_body(int D) { return D == 2 ? (int)sizeof(Body<2>) : (int)sizeof(Body<3>); }
 double ref_G() { return G; }

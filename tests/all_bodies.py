@@ -77,7 +77,7 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
         assert rec["strict_vs_oracle_max_backward"] <= TOL_STRICT_BACKWARD, rec
         assert rec["magnitude_sums_vs_oracle_max_rel"] <= 1.0e-5, rec
         c.set_tuning(0, _variant(nbx, "strict_f64_t4"))
-        rec["strict_ms"] = _timed(c)
+        rec["strict_ms"] = _timed(c, 1)
         rec["strict_kernel_ms"] = c.kernel_time()[0]
         assert np.array_equal(c.forces(G), fs), "the magnitude-sum build must not change the forces"
         # 2. the default fp32 path, ALL bodies against the strict result
@@ -107,7 +107,7 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
     over = rel_f > 0.5 * refine_tol
     rec["sigma_needed"]["max_among_rel_gt_half_tol"] = float(need[over].max()) if over.any() else None
     rec["sigma_needed"]["n_rel_gt_half_tol"] = int(over.sum())
-    for sf in (4.0, 6.0, 8.0, 12.0, 16.0, 24.0):
+    for sf in (12.0, 24.0, 32.0, 40.0, 48.0, 64.0, 96.0):
         flagged = spread * u * sf > refine_tol
         rec[f"rule_sigma_{sf:g}"] = dict(flagged=int(flagged.sum()), missed_over_tol=int((~flagged & (rel_f > refine_tol)).sum()),
                                          worst_unflagged_rel=float(rel_f[~flagged].max()) if (~flagged).any() else 0.0)

@@ -13,6 +13,10 @@ see oracle/ref_driver.cpp) -- data, not source.  Files are numpy .npz (no pickle
   octree_direct_D{2,3}_N512.npz  (python tests/golden/make_golden.py octree) fp32-representable bodies and the forces of
                                  the reference's Barnes-Hut octree walked with theta = 0 (octree.cpp:105-125 reached for
                                  every pair): the tree codes' attractive leaf law, SURVEY 8f-4
+  bvh_leaves_D{2,3}_N4096.npz,   (python tests/golden/make_golden.py bvh) fp32-representable bodies, the LEAVES of the reference's
+  bvh_leaves_D3_N3000.npz        own BVH<D>(bodies, 16) read through its public root (bvh.h:91-103, bvh.cpp:16-126) as CSR arrays,
+                                 and per body the sum over all leaves of BVH<D>::calculate_force(body, leaf) (bvh.cpp:143-176):
+                                 the tree codes' near-field sums on a reference-built tree (N = 3000: ragged leaves of 11-12)
 """
 import os
 import subprocess
@@ -48,12 +52,30 @@ def octree(ref):
                             forces_octree_theta0=ref.octree_direct_forces(b), forces_brute_seq=ref.brute_force(0, b))
 
 
+def bvh(ref):
+    for dim, n in ((2, 4096), (3, 4096), (3, 3000)):
+        b = round_f32(ref.generate(SEED + 3 + dim, n, dim), dim)
+        b[21, :dim] = (50.0, 60.0, 70.0)[:dim]
+        b[20, :dim] = b[21, :dim]
+        b[20, 0] += 2.0e-5                        # a pair at r^2 = 3.6e-10: skipped by the leaf law (< 1e-9, bvh.cpp:164)
+        b[30, :dim] = b[31, :dim]                 # and an exact duplicate (the "same position" skip, bvh.cpp:151-158)
+        b = round_f32(b, dim)
+        offs, idx = ref.bvh_leaves(b, 16)
+        assert offs[-1] == n and np.array_equal(np.sort(idx), np.arange(n))
+        np.savez_compressed(os.path.join(HERE, f"bvh_leaves_D{dim}_N{n}.npz"), bodies_f32=b, G=np.float64(ref.G()),
+                            max_bodies_per_leaf=np.int64(16), leaf_offsets=offs, leaf_bodies=idx,
+                            forces_bvh_all_leaves=ref.bvh_leaf_forces(b, 16))
+
+
 def main():
     subprocess.check_call([os.path.join(ROOT, "oracle", "build_ref.sh")])
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Reference()
     if len(sys.argv) > 1 and sys.argv[1] == "octree":
         octree(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "bvh":
+        bvh(ref)
         return
     assert ref.sizeof_body(3) == 56 and ref.sizeof_body(2) == 40
     for dim in (2, 3):
@@ -99,6 +121,7 @@ def main():
     out["two_after_step_dt1"] = s
     np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
     octree(ref)
+    bvh(ref)
     print("golden vectors written to", HERE)
 
 

@@ -45,12 +45,11 @@ def _worker(rank, world, port, n, dim, steps, dt, gscale, outdir):
         broken = sysm.verify_exchange(bodies)
         be.start_exchange = real_start
         assert sysm.verify_exchange(bodies) == 0           # and the buffers are whole again
-        # a collective that RAISES on one rank only: every rank must still meet in the bookkeeping reduction (on a group of
-        # its own) and every rank must end with ExchangeError -- nobody retries on a communicator that may be wedged
+        # a collective that RAISES on one rank only: every rank must still meet in the bookkeeping (through the rendezvous
+        # store, a transport of its own) and every rank must end with ExchangeError -- nobody retries on a communicator that may be wedged
         raised = 0
         if world > 1:
-            chk = dist.new_group(backend="gloo")
-            sysc = pkg.dist.ShardedNBody(be, layout, check_group=chk)
+            sysc = pkg.dist.ShardedNBody(be, layout, check_store=dist.distributed_c10d._get_default_store())
             real_finish = be.finish_exchange
 
             def finish_raising_on_rank0(work):

@@ -51,9 +51,10 @@ def test_config2_n65536(nbx, oracle):
 
 
 def test_config2_leapfrog_100_steps(nbx, oracle):
-    """BASELINE config 2: 100 leapfrog steps at N=65,536.  Full-trajectory oracle is out of reach
-    (100 x 4.3e9 pairs on the CPU); checked: ballistic prediction (forces are ~1e-20, so x(t) =
-    x0 + v0*t to ~1e-15), masses untouched, and a 3-step prefix of sampled bodies against the oracle."""
+    """BASELINE config 2: 100 leapfrog steps at N=65,536 with the reference's G.  A full-trajectory oracle is out of reach
+    (100 x 4.3e9 pairs on the CPU) and would show nothing: the forces are ~1e-20, so the motion is ballistic, x(t) = x0 + v0*t
+    to ~1e-15 -- which is what is checked here, with the masses untouched.  The trajectory under a coupling that bends the
+    paths is test_config2_trajectory_with_coupling below."""
     n, dim, dt = 65536, 3, 5.0
     b0 = oracle.round_inputs_to_f32(oracle.generate(7, n, dim))
     got = b0.copy()
@@ -62,6 +63,39 @@ def test_config2_leapfrog_100_steps(nbx, oracle):
     ballistic = b0[:, :dim] + b0[:, dim:2 * dim] * (100 * dt)
     assert np.allclose(got[:, :dim], ballistic, rtol=1e-12, atol=0)
     assert np.abs(got[:, dim:2 * dim] - b0[:, dim:2 * dim]).max() < 1e-12
+
+
+def test_config2_trajectory_with_coupling(nbx, oracle):
+    """BASELINE config 2's size with a coupling that matters: G scaled by 1e24 so the forces bend the paths (the closest
+    pairs gain several units of velocity per step against initial speeds of <= 10), 3 kick/drift steps on the device, and
+    EVERY one of the 65,536 bodies against a host loop built from the oracle's leaves -- update_body_velocities /
+    update_body_positions (methods.cpp:425-450) fed the oracle's brute_force_omp_2 forces (3 x 4.3e9 pairs) on the
+    fp32-representable positions the device's force kernel sees.  Per-body bound from the stated force tolerance (T1):
+    |dv_i| <= steps * 4e-6 * S_i/m_i * dt, S_i = sum_j |f_ij| on the initial state (+25 % for its drift over the steps)."""
+    n, dim, steps, dt, scale = 65536, 3, 3, 2.0, 1e24
+    Gs = oracle.G * scale
+    b0 = oracle.round_inputs_to_f32(oracle.generate(2, n, dim))
+    S0 = oracle.force_magnitude_sums(b0) * scale
+    ref = b0.copy()
+    for _ in range(steps):
+        f = oracle.brute_force_omp_2(oracle.round_inputs_to_f32(ref)) * scale
+        oracle.update_body_velocities(ref, np.ascontiguousarray(f), dt)
+        oracle.update_body_positions(ref, dt)
+    got = b0.copy()
+    nbx.leapfrog_hip_n_body(got, dt, steps, Gs)
+    dv_ref = np.linalg.norm(ref[:, dim:2 * dim] - b0[:, dim:2 * dim], axis=1)
+    assert np.median(dv_ref) > 1e-3 and dv_ref.max() > 1.0, "coupling too weak to test anything"
+    err_v = np.linalg.norm(got[:, dim:2 * dim] - ref[:, dim:2 * dim], axis=1)
+    bound = 1.25 * steps * TOL_BACKWARD * S0 / b0[:, -1] * dt
+    worst = float((err_v / bound).max())
+    assert worst <= 1.0, f"velocity error {worst:.2f} x the per-body bound"
+    assert (err_v <= 2e-5 * dv_ref.max()).all()
+    # positions: x += v*dt with the device's own (fp64) velocities; error = the velocity error integrated
+    err_x = np.linalg.norm(got[:, :dim] - ref[:, :dim], axis=1)
+    assert (err_x <= steps * dt * bound + 1e-9 * np.linalg.norm(ref[:, :dim], axis=1)).all()
+    assert np.array_equal(got[:, -1], b0[:, -1])
+    print(f"\nconfig 2 with coupling: median |dv| {np.median(dv_ref):.3e}, max |dv| {dv_ref.max():.3e}; velocity error <= {worst:.2f} of the "
+          f"per-body bound, max {err_v.max():.3e}; max position error {err_x.max():.3e}")
 
 
 def test_config3_n1048576_sampled_rows_and_properties(nbx, oracle):

@@ -50,6 +50,38 @@ def test_reference_octree_golden(nbx, oracle, dim):
     assert np.allclose(fb[10], g["forces_brute_seq"][10], rtol=1e-4, atol=0)         # ... and counted by the brute-force law
 
 
+@pytest.mark.parametrize("dim,n", ((2, 4096), (3, 4096), (3, 3000)))
+def test_reference_bvh_golden(nbx, oracle, dim, n):
+    """Leaves of the REFERENCE's own BVH<D>(bodies, 16) (read through its public root, bvh.h:91-103) as the CSR arrays of the
+    call, every leaf on every list, the tree codes' leaf law: the device reproduces the reference BVH's own near-field sums
+    (per body, BVH::calculate_force(body, leaf) over all leaves, bvh.cpp:143-176; committed by tests/golden/make_golden.py)
+    within the stated fp32 tolerance, and the oracle restatement matches them to 1e-12.
+    NBX_LAW_FMM_P2P stays PARITY-UNPINNED: FMM_Parlay<D>'s constructor leaves its tree pointing into a destroyed local
+    vector (fmm_parlay.cpp:16-22 with fmm.cpp:389-395), so the reference's p2p_phase cannot be executed to produce a vector;
+    that law is checked against its restatement (fmm_parlay.cpp:992-1020) and hand-computed known answers only."""
+    g = golden(f"bvh_leaves_D{dim}_N{n}.npz")
+    b = np.ascontiguousarray(g["bodies_f32"])
+    lo, lb = g["leaf_offsets"], g["leaf_bodies"]
+    nl = lo.size - 1
+    leaves = (lo, lb, np.arange(nl + 1, dtype=np.uint32) * nl, np.tile(np.arange(nl, dtype=np.uint32), nl))
+    ref = g["forces_bvh_all_leaves"]
+    f = nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_TREE_LEAF, G=float(g["G"]))
+    S = oracle.leaf_pair_magnitude_sums(b, leaves, 1)
+    e = assert_force_parity(f, ref, S, f"reference BVH leaves D={dim} N={n}")
+    orc = oracle.leaf_pair_forces(b, leaves, 1)
+    assert np.abs(orc - ref).max() <= 1e-12 * np.abs(ref).max()
+    # the planted sub-threshold pair (r^2 = 3.6e-10) and the exact duplicate are skipped, as the reference skips them
+    for i in (20, 21, 30, 31):
+        assert np.allclose(f[i], ref[i], rtol=1e-4, atol=0), i
+    # a near-field list (each leaf + the leaves whose boxes come within one leaf diagonal): against the pinned restatement
+    cen = np.array([b[lb[lo[l]:lo[l + 1]], :dim].mean(axis=0) for l in range(nl)])
+    diag = np.array([np.linalg.norm(np.ptp(b[lb[lo[l]:lo[l + 1]], :dim], axis=0)) for l in range(nl)])
+    near = [np.r_[l, np.setdiff1d(np.nonzero(np.linalg.norm(cen - cen[l], axis=1) < 1.5 * (diag[l] + diag.mean()))[0], [l])] for l in range(nl)]
+    so = np.r_[0, np.cumsum([len(x) for x in near])].astype(np.uint32)
+    _check(nbx, oracle, b, (lo, lb, so, np.concatenate(near).astype(np.uint32)), 1, f"near-field lists on reference BVH leaves D={dim}")
+    print(f"\nreference BVH leaves D={dim} N={n}: {nl} leaves of {np.diff(lo).min()}-{np.diff(lo).max()} bodies, errors {e}")
+
+
 def test_all_pairs_lists_equal_the_brute_force_path(nbx, oracle):
     """Every leaf on every list: the leaf kernel under the brute-force law must agree with the all-pairs kernel."""
     n, dim = 6000, 3

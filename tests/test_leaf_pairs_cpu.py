@@ -1,7 +1,10 @@
 """CPU: SURVEY 8(f-4), the leaf-pair direct-sum oracle (oracle_leaf_pair_forces) and its host-side plumbing.
-Law 1 (tree leaf) is pinned to the reference's own Barnes-Hut octree walked with theta = 0 -- live where oracle/_ref
-exists, and through the committed golden outputs of that walk everywhere; law 0 is the brute-force oracle again;
-law 2 (FMM P2P) is a restatement only (parity unpinned: executing FMM_Parlay is undefined behaviour, see the oracle)."""
+Law 1 (tree leaf) is pinned twice: to the reference's own Barnes-Hut octree walked with theta = 0, and to the reference's own
+BVH -- the leaves of BVH<D>(bodies, 16) read through its public root, and per body the sum of BVH::calculate_force(body, leaf)
+over all of them (bvh.cpp:143-176) -- live where oracle/_ref exists, and through committed golden outputs everywhere;
+law 0 is the brute-force oracle again; law 2 (FMM P2P) is a restatement only (PARITY UNPINNED: executing FMM_Parlay is
+undefined behaviour -- its constructor leaves the tree pointing into a destroyed vector, fmm_parlay.cpp:16-22 -- so the
+reference cannot produce a vector to pin it to; see the oracle)."""
 import numpy as np
 import pytest
 
@@ -33,6 +36,43 @@ def test_tree_leaf_law_matches_live_reference_octree(oracle, reference, dim):
     f = oracle.leaf_pair_forces(b, _one_leaf(900), 1)
     ref = reference.octree_direct_forces(b)
     assert np.abs(f - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def every_leaf_lists(n_leaves):
+    """Every leaf on every target leaf's list, own leaf included: list_offsets, list_sources."""
+    return (np.arange(n_leaves + 1, dtype=np.uint32) * n_leaves, np.tile(np.arange(n_leaves, dtype=np.uint32), n_leaves))
+
+
+@pytest.mark.parametrize("dim,n", ((2, 4096), (3, 4096), (3, 3000)))
+def test_tree_leaf_law_on_the_reference_bvh_golden(oracle, dim, n):
+    """Leaves of a reference-BUILT tree (multi-body, ragged at N = 3000) and the reference BVH's own leaf sums."""
+    g = golden(f"bvh_leaves_D{dim}_N{n}.npz")
+    b = np.ascontiguousarray(g["bodies_f32"])
+    lo, lb = g["leaf_offsets"], g["leaf_bodies"]
+    sizes = np.diff(lo)
+    assert lo[-1] == n and sizes.max() <= 16 and sizes.min() >= 8 and np.array_equal(np.sort(lb), np.arange(n))
+    ref = g["forces_bvh_all_leaves"]
+    f = oracle.leaf_pair_forces(b, (lo, lb) + every_leaf_lists(lo.size - 1), 1)
+    assert np.abs(f - ref).max() <= 1e-12 * np.abs(ref).max()          # per-leaf partial sums vs one running sum
+    # with every leaf on every list it is the all-pairs sum under the leaf law: equal to the octree-pinned single-leaf form
+    one = oracle.leaf_pair_forces(b, _one_leaf(n), 1)
+    assert np.abs(f - one).max() <= 1e-12 * np.abs(ref).max()
+    # the planted pairs: r^2 = 3.6e-10 and an exact duplicate are skipped by the leaf law (bvh.cpp:151-164)
+    d2 = ((b[20, :dim] - b[21, :dim]) ** 2).sum()
+    assert 1e-10 < d2 < 1e-9 and np.array_equal(b[30, :dim], b[31, :dim]) and np.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("dim", (2, 3))
+def test_tree_leaf_law_on_the_live_reference_bvh(oracle, reference, dim):
+    n = 2500
+    b = oracle.round_inputs_to_f32(oracle.generate(41 + dim, n, dim))
+    lo, lb = reference.bvh_leaves(b, 16)
+    ref = reference.bvh_leaf_forces(b, 16)
+    f = oracle.leaf_pair_forces(b, (lo, lb) + every_leaf_lists(lo.size - 1), 1)
+    assert np.abs(f - ref).max() <= 1e-12 * np.abs(ref).max()
+    lo8, lb8 = reference.bvh_leaves(b, 5)                               # another leaf capacity: other tree, same sums
+    f8 = oracle.leaf_pair_forces(b, (lo8, lb8) + every_leaf_lists(lo8.size - 1), 1)
+    assert np.diff(lo8).max() <= 5 and np.abs(f8 - reference.bvh_leaf_forces(b, 5)).max() <= 1e-12 * np.abs(ref).max()
 
 
 def test_fmm_p2p_smoothing_known_answers(oracle):
