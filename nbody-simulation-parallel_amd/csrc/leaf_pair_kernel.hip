@@ -8,15 +8,14 @@
 //
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
 // forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
-// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: one workgroup (one wave64 when the mean
-// leaf holds <= 80 bodies, else two) owns up to 64 (128) targets of ONE leaf and walks that leaf's source-leaf list as one
-// stream of bodies staged through LDS in tiles of one body per lane {x,y,z,m}; fp32 sums per tile, flushed into fp64
-// second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
-// once.  The comment at the kernel says how the lanes share the work.  Leaves are small (the reference caps them at 100
-// bodies, methods.h:26), so the launch is tens of thousands of short workgroups; HBM traffic is 16 B per (target block,
-// source body) served mostly from L2.  VALU-issue-bound (counters: profiles/r2/pmc_leaf_pair_kernel.txt): 76 % of the
-// instructions are the pair loop, the rest stages tiles and flushes sums; tiles of 256 bodies instead of 64, or half the
-// LDS reads, changed nothing measurable.
+// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: ONE WAVE64 owns up to 128
+// targets of one leaf -- two per lane, held as packed fp32 pairs like the brute-force kernel's -- and that leaf's whole
+// source-leaf list, staged through LDS leaf by leaf; fp32 sums over at most 256 terms, flushed into fp64 accumulators.
+// No atomics, a fixed summation order, every output written once.  The comment at the kernel says how the lanes share
+// the work.  Leaves are small (the reference caps them at 100 bodies, methods.h:26), so the launch is tens of thousands
+// of short single-wave workgroups; HBM traffic is 16 B per (target block, source body), served mostly from L2.
+// VALU-issue-bound: 14 VALU per source and lane (= per two pair terms), ~12 % on top for staging, flushes and the
+// prologue (round 2's kernel: 16 per two terms, 24 % on top, 4-way LDS bank conflicts on its tile writes).
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 
@@ -27,11 +26,11 @@ using namespace nbx;
 
 namespace {
 
-// targets per workgroup = source bodies per LDS tile: 128 lanes (two wave64), or one wave64 when the leaves are small
-// (the mean leaf of the reference's trees is well under 100 bodies, methods.h:26) so that fewer lanes idle
-constexpr int kLeafBlock = 128;
-constexpr int kLeafBlockSmall = 64;
-constexpr int kMaxLanesPerTarget = 8;   // a block of few targets gives each up to this many lanes (they split the sources)
+constexpr int kWave = 64;               // lanes per workgroup: one wave64
+constexpr int kTargetsPerBlock = 128;   // two targets per lane
+constexpr int kMaxGroups = 16;          // lane groups that split the sources of a block with few targets
+constexpr int kLeafTile = 64;               // source bodies per LDS tile
+constexpr int kLeafTileSlots = 96;          // float4 slots per tile buffer: groups x (padded) bodies per group <= 81
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
 constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
@@ -40,11 +39,12 @@ constexpr float kNormZeroF = 0x1.79ca12p-67f;   // 1.00000005e-20 (vector.h:93-9
 constexpr float kSameF = 1.0e-14f;              // largest fp32 <= 1e-14 (fmm_parlay.cpp:995-1000: |d_k| > 1e-14 -> distinct)
 static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double)kNormZeroF >= 1e-20 && (double)kSameF <= 1e-14,
               "fp32 thresholds must sit on the right side of the fp64 ones");
+constexpr float kFar = 1.0e18f;                 // pad bodies: sources at +kFar, pad targets at -kFar (r^2 ~ 1e37, weight underflows to 0)
 
 struct TargetBlock {
     uint32_t leaf;     // target leaf
     uint32_t first;    // first target slot (leaf order)
-    uint32_t count;    // <= the launch's block size
+    uint32_t count;    // <= kTargetsPerBlock
 };
 
 struct LeafArgs {
@@ -90,170 +90,240 @@ __device__ __forceinline__ constexpr float law_special_below() {
     return LAW == NBX_LAW_BRUTE ? kR2SkipF : LAW == NBX_LAW_TREE_LEAF ? kTreeSkipF : kSmoothF;
 }
 
-// One workgroup = up to BLOCK targets of one leaf against that leaf's source list.
-//  * The list is read ONCE, by the lanes in parallel (lane k: list entry k -> that source leaf's slot range), and turned
-//    into one stream of source bodies by a prefix sum over the leaf sizes in LDS; tiles are then cut from the STREAM
-//    (BLOCK consecutive stream positions, whatever leaves they fall in), not from single leaves.  Walking the list leaf
-//    by leaf cost a chain of three dependent loads per ~30-body tile and left half of every tile empty.
-//  * Two SOURCES per lane and iteration, as packed fp32 pairs (v_pk_add/fma/mul_f32: 3 + 3 + 2 + 3 packed instructions and
-//    two v_rcp_f32 for two pairs, where one source at a time took 12 scalar ones and a v_rcp per pair).  The tile is
-//    staged in LDS as source PAIRS {xa,xb,ya,yb},{za,zb,ma,mb}, so each ds_read_b128 lands in aligned register pairs.
-//  * The law's special cases (skip / smoothing below ~1e-5 separation, and a body meeting itself in its own leaf) are
-//    rare: one v_cmp per pair and a wave-wide vote; only a wave in which some lane sees r^2 below the law's threshold
-//    takes the guarded scalar weights (leaf_weight) for that source pair -- which is every pair of the target's own leaf
-//    (each source there is some lane's own body) and next to nothing else.
-//  * Leaves are small (the reference caps them at 100 bodies; a uniform grid at 32 per leaf leaves half of a wave64 idle
-//    with one lane per target): a block whose targets fill at most half / a quarter of the lanes gives each target 2 / 4
-//    lanes, which split the source pairs of every tile between them; their fp64 sums meet in LDS at the end, in lane
-//    group order (deterministic).
-template <int D, int LAW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[BLOCK + 2 * kMaxLanesPerTarget];   // BLOCK/2 source pairs x 2 float4, + pad pairs past the end
-    __shared__ double red[3][BLOCK];
-    __shared__ uint32_t seg_end[BLOCK];     // stream position one past the last body of list entry k (inclusive prefix sum)
-    __shared__ uint32_t seg_first[BLOCK];   // slot of stream position 0 if entry k started there: slot = seg_first[k] + position
-    const unsigned tid = threadIdx.x;
+// One wave64 = up to 128 targets of one leaf against that leaf's source list.
+//  * TWO TARGETS PER LANE as packed fp32 pairs (lane p holds targets p and p + L of the block, L = ceil(count / 2)), every
+//    source a broadcast: per source and lane 3 v_pk_add (d), v_pk_mul + 2 v_pk_fma (r^2), 2 v_rcp, 2 v_pk_mul (w^2, .m with
+//    the op_sel form of the brute-force kernel), 3 v_pk_fma (accumulate) and one v_min3 = 14 VALU per two pair terms.
+//  * A block of few targets (L <= 32 lanes) runs G = floor(64 / L) <= 16 LANE GROUPS that split the sources of every tile
+//    G ways; their fp64 sums meet in LDS at the end, in group order (deterministic).  The host cuts a leaf into the number
+//    of blocks that minimises (blocks) x (sources) x (14 / G + staging) -- e.g. 34 targets: two blocks of 17 at 7 groups
+//    instead of one at 3.
+//  * The tile is laid out GROUP-MAJOR in LDS (body q of the tile at slot (q mod G) * TGp + q / G, TGp odd): lane group g
+//    reads consecutive 16-byte slots with immediate offsets -- no address arithmetic in the pair loop, distinct groups on
+//    distinct banks -- one ds_read_b128 per source and lane, one conflict-free ds_write_b128 per staged body.
+//  * The source list is staged LEAF BY LEAF, not body by body: lane e holds list entry e (source leaf -> slot range), the
+//    wave walks the entries with v_readlane, and a leaf's bodies go from one 16-byte global load per lane straight to their
+//    tile slots; two leaves are in flight while a tile is consumed.  (Round 2 turned the list into a body stream by a
+//    prefix sum in LDS and searched the entry of every staged body: 24 % of its instructions.)
+//  * The law's special cases (skip / smoothing below ~1e-5 separation) and a body meeting itself cost nothing in the common
+//    path: the v_min3 keeps the smallest r^2 a lane saw in the tile; tiles that hold bodies of the target's own leaf, and
+//    any tile after which some lane's minimum lies below the law's threshold (the sums are then put back to what they
+//    were before the tile), go through the GUARDED loop -- a compare and select per pair term, and for the FMM law the
+//    smoothing branch behind a wave vote.
+template <int D, int LAW>
+__global__ __launch_bounds__(kWave) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[2][kLeafTileSlots];
+    __shared__ double red[6][kWave];
+    const unsigned lane = threadIdx.x;
     const TargetBlock tb = a.blocks[blockIdx.x];
-    // lanes per target: as many whole groups of `count` lanes as the block holds (21 targets in a wave64: 3 lanes each)
-    const unsigned W = tb.count ? tb.count : 1u;
-    const unsigned fit = (unsigned)BLOCK / W;
-    const unsigned P = fit < (unsigned)kMaxLanesPerTarget ? fit : (unsigned)kMaxLanesPerTarget;
-    const unsigned t = tid % W, g_raw = tid / W;
-    const bool valid = g_raw < P;                              // lanes left over compute along with group 0, unused
+    // ---- block geometry (wave-uniform) ----
+    const unsigned c = tb.count;
+    const unsigned L = (c + 1u) >> 1;
+    const unsigned fit = (unsigned)kWave / (L ? L : 1u);
+    const unsigned G = fit < (unsigned)kMaxGroups ? fit : (unsigned)kMaxGroups;
+    const unsigned TG = ((unsigned)kLeafTile + G - 1u) / G;
+    const unsigned TGp = TG | 1u;                               // odd: lane groups land on distinct LDS banks
+    const unsigned inv_g = 65536u / G + 1u;                     // q / G = (q * inv_g) >> 16 for q < 128
+    const unsigned p = lane % L, g_raw = lane / L;
+    const bool valid = g_raw < G;                               // lanes left over compute along with group 0, unused
     const unsigned g = valid ? g_raw : 0u;
-    const uint32_t slot = tb.first + (valid ? t : 0u);
-    const float4 me = a.xm[slot];
-    const float ix = me.x, iy = me.y, iz = (D == 3) ? me.z : 0.0f;
-    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-    double ox = 0.0, oy = 0.0, oz = 0.0;
-    float* const tf = reinterpret_cast<float*>(tile);
-    const unsigned wr = (tid >> 1) * 8u + (tid & 1u);      // source tid = half (tid & 1) of pair tid / 2
-    // the lane groups stride through the tile's pairs P at a time: the last trip may reach up to P - 1 pairs past the
-    // tile -- massless bodies far away, staged once
-    if (tid < 2u * (unsigned)kMaxLanesPerTarget)
-        tile[BLOCK + tid] = (tid & 1u) ? make_float4((D == 3) ? 1.0e18f : 0.0f, (D == 3) ? 1.0e18f : 0.0f, 0.f, 0.f) : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 1.0e18f);
-    const uint32_t e1 = a.list_offsets[tb.leaf + 1];
-    // the list in chunks of BLOCK entries (one chunk for every list the reference's trees produce); all workgroup-uniform
-    for (uint32_t e0 = a.list_offsets[tb.leaf]; e0 < e1; e0 += (uint32_t)BLOCK) {
-        const unsigned n_ent = (e1 - e0 < (uint32_t)BLOCK) ? (unsigned)(e1 - e0) : (unsigned)BLOCK;
-        uint32_t first = 0, len = 0;
-        if (tid < n_ent) {
-            const uint32_t s = a.list_sources[e0 + tid];
-            first = a.leaf_offsets[s];
-            len = a.leaf_offsets[s + 1] - first;
+    const bool has1 = p + L < c;
+    const float4 me0 = a.xm[tb.first + p];
+    const float4 me1 = has1 ? a.xm[tb.first + p + L] : make_float4(-kFar, -kFar, (D == 3) ? -kFar : 0.0f, 0.0f);
+    const f2 ix = {me0.x, me1.x}, iy = {me0.y, me1.y}, iz = {(D == 3) ? me0.z : 0.0f, (D == 3) ? me1.z : 0.0f};
+    double o[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};               // fp64 sums: x0 x1 y0 y1 z0 z1
+    f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};       // fp32 sums since the last flush
+    unsigned pending = 0;                                       // terms in them
+    const float4 pad = make_float4(kFar, kFar, (D == 3) ? kFar : 0.0f, 0.0f);
+    auto slot_of = [&](unsigned q) -> unsigned {                // body q of a tile -> its float4 slot
+        const unsigned qd = (q * inv_g) >> 16;
+        return (q - qd * G) * TGp + qd;
+    };
+
+    // ---- the pair loops over one staged tile: `trips` sources per lane group ----
+    auto flush = [&]() {
+        o[0] += (double)ax.x; o[1] += (double)ax.y; o[2] += (double)ay.x; o[3] += (double)ay.y;
+        if (D == 3) { o[4] += (double)az.x; o[5] += (double)az.y; }
+        ax = ay = az = f2{0.f, 0.f};
+        pending = 0;
+    };
+    auto fast4 = [&](const float4* __restrict__ src, float& rmin) {   // four sources, stage by stage (four independent chains)
+        f2 dx[4], dy[4], dz[4], r2[4], w[4], szm[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 s = src[q];
+            szm[q] = f2{s.z, s.w};
+            dx[q] = f2{s.x, s.x} - ix;
+            dy[q] = f2{s.y, s.y} - iy;
+            dz[q] = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
         }
-        __syncthreads();                                   // the previous chunk's last tile and tables are done with
-        seg_end[tid] = len;
-        __syncthreads();
-        for (unsigned d = 1; d < (unsigned)BLOCK; d <<= 1) {   // inclusive prefix sum (Hillis-Steele)
-            const uint32_t add = (tid >= d) ? seg_end[tid - d] : 0u;
-            __syncthreads();
-            seg_end[tid] += add;
-            __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r2[q] = dx[q] * dx[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r2[q] = __builtin_elementwise_fma(dy[q], dy[q], r2[q]);
+        if (D == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r2[q] = __builtin_elementwise_fma(dz[q], dz[q], r2[q]);
         }
-        const uint32_t my_end = seg_end[tid];
-        seg_first[tid] = first - (my_end - len);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rmin = __builtin_fminf(__builtin_fminf(rmin, r2[q].x), r2[q].y);   // v_min3_f32
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r2[q] = w[q] * w[q];
+        // the mass is the HIGH half of the source's {z, m} register pair: op_sel spelled out (force_kernel.hip), applied to
+        // w^2 (plain code, hazards handled by the compiler), never directly to a v_rcp result
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w[q]) : "v"(szm[q]), "v"(r2[q]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ax = __builtin_elementwise_fma(w[q], dx[q], ax);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ay = __builtin_elementwise_fma(w[q], dy[q], ay);
+        if (D == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) az = __builtin_elementwise_fma(w[q], dz[q], az);
+        }
+    };
+    auto fast1 = [&](const float4 s, float& rmin) {
+        const f2 dx = f2{s.x, s.x} - ix, dy = f2{s.y, s.y} - iy, dz = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
+        f2 r2 = dx * dx;
+        r2 = __builtin_elementwise_fma(dy, dy, r2);
+        if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
+        rmin = __builtin_fminf(__builtin_fminf(rmin, r2.x), r2.y);
+        f2 w = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+        w = w * w;
+        w = w * f2{s.w, s.w};
+        ax = __builtin_elementwise_fma(w, dx, ax);
+        ay = __builtin_elementwise_fma(w, dy, ay);
+        if (D == 3) az = __builtin_elementwise_fma(w, dz, az);
+    };
+    auto guarded1 = [&](const float4 s) {   // exact law per pair term: compare and select; FMM smoothing behind a wave vote
+        const f2 dx = f2{s.x, s.x} - ix, dy = f2{s.y, s.y} - iy, dz = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
+        f2 r2 = dx * dx;
+        r2 = __builtin_elementwise_fma(dy, dy, r2);
+        if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
+        f2 w;
+        constexpr float T = law_special_below<LAW>();
+        if (LAW == NBX_LAW_FMM_P2P &&
+            (__builtin_amdgcn_ballot_w64(r2.x < T && r2.x > 0.0f) | __builtin_amdgcn_ballot_w64(r2.y < T && r2.y > 0.0f)) != 0ull) {
+            w = f2{leaf_weight<D, LAW>(r2.x, s.w, dx.x, dy.x, dz.x), leaf_weight<D, LAW>(r2.y, s.w, dx.y, dy.y, dz.y)};
+        } else {   // below the threshold: skipped (brute force, tree leaf), or the same position (FMM: r^2 = 0) -- weight 0
+            const f2 r2g = {(r2.x < T) ? __builtin_inff() : r2.x, (r2.y < T) ? __builtin_inff() : r2.y};
+            w = f2{__builtin_amdgcn_rcpf(r2g.x), __builtin_amdgcn_rcpf(r2g.y)};
+            w = w * w;
+            w = w * f2{s.w, s.w};
+        }
+        ax = __builtin_elementwise_fma(w, dx, ax);
+        ay = __builtin_elementwise_fma(w, dy, ay);
+        if (D == 3) az = __builtin_elementwise_fma(w, dz, az);
+    };
+    auto consume = [&](int buf, unsigned cnt, bool own_leaf_inside) {   // all arguments wave-uniform
+        const unsigned trips = (cnt + G - 1u) / G;
+        if (lane < trips * G - cnt) tile[buf][slot_of(cnt + lane)] = pad;   // fill the last trip: massless bodies far away
         __syncthreads();
-        const uint32_t total = seg_end[BLOCK - 1];         // bodies in this chunk's stream
-        // Tiles of the stream, software-pipelined: the next tile's global loads are issued before the current tile is
-        // consumed, so their latency hides behind the pair loop.
-        unsigned k = 0;                                    // this lane's list entry; only ever moves forward
-        auto load = [&](uint32_t pos) -> float4 {
-            // positions past the stream's end stage a massless body far away: it pads the last tile to whole pairs and
-            // contributes exactly 0 under every law (r^2 ~ 1e36 is finite in fp32, w = 0 * r^-4)
-            float4 v = make_float4(1.0e18f, 1.0e18f, (D == 3) ? 1.0e18f : 0.0f, 0.f);
-            if (pos < total) {
-                while (pos >= seg_end[k]) ++k;             // empty leaves are stepped over here as well
-                const uint32_t j = seg_first[k] + pos;
-                v = a.xm[j];
+        if (pending + trips > 256u) flush();
+        const float4* __restrict__ src = &tile[buf][g * TGp];
+        bool guard = own_leaf_inside;
+        if (!guard) {
+            const f2 sx = ax, sy = ay, sz = az;
+            float rmin = __builtin_inff();
+            unsigned k = 0;
+            for (; k + 4u <= trips; k += 4u) fast4(src + k, rmin);
+            for (; k < trips; ++k) fast1(src[k], rmin);
+            guard = __builtin_amdgcn_ballot_w64(!(rmin >= law_special_below<LAW>())) != 0ull;   // a NaN r^2 also lands here
+            if (guard) { ax = sx; ay = sy; az = sz; }          // rare: this tile's terms are taken back and redone below
+        }
+        if (guard)
+            for (unsigned k = 0; k < trips; ++k) guarded1(src[k]);
+        pending += trips;
+        __syncthreads();                                       // the tile is free again
+    };
+
+    // ---- the source list, leaf by leaf ----
+    // (sub-)entries in flight: a leaf of more than 64 bodies is staged in pieces of 64
+    const uint32_t e_end = a.list_offsets[tb.leaf + 1];
+    uint32_t e_base = a.list_offsets[tb.leaf];                 // first list entry of the chunk held in the lanes
+    unsigned n_ent = 0, e_next = 0;                            // entries in the chunk, next one to issue
+    uint32_t v_first = 0, v_len = 0, v_src = 0, off_next = 0;  // lane e: entry e_base + e
+    auto load_chunk = [&]() {
+        n_ent = (e_end - e_base < (uint32_t)kWave) ? (unsigned)(e_end - e_base) : (unsigned)kWave;
+        v_first = v_len = 0; v_src = 0xffffffffu;
+        if (lane < n_ent) {
+            v_src = a.list_sources[e_base + lane];
+            v_first = a.leaf_offsets[v_src];
+            v_len = a.leaf_offsets[v_src + 1] - v_first;
+        }
+        e_next = 0; off_next = 0;
+    };
+    struct Piece { float4 v; unsigned n; bool own; };
+    auto issue = [&]() -> Piece {                              // wave-uniform control; the load stays in flight
+        Piece pc{pad, 0u, false};
+        for (;;) {
+            if (e_next == n_ent) {
+                e_base += n_ent;
+                n_ent = e_next = 0;
+                if (e_base >= e_end) return pc;                // the list is exhausted: an empty piece, again and again
+                load_chunk();
+                continue;
             }
-            return v;
-        };
-        float4 nxt = load(tid);
-        // fp32 sums run over up to 256 terms per lane (as in the brute-force kernel's tiles) before they are flushed into
-        // the fp64 accumulators: with P lanes per target that is several tiles -- a flush per 64-body tile was 6
-        // conversions and 6 fp64 additions against as little as 8 trips of pair arithmetic
-        f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
-        unsigned pending = 0;                                  // terms in the fp32 sums since the last flush
-        for (uint32_t pos0 = 0; pos0 < total; pos0 += (uint32_t)BLOCK) {
-            const uint32_t cur = (total - pos0 < (uint32_t)BLOCK) ? total - pos0 : (uint32_t)BLOCK;
-            __syncthreads();                                   // previous tile fully consumed
-            tf[wr] = nxt.x; tf[wr + 2] = nxt.y; tf[wr + 4] = nxt.z; tf[wr + 6] = nxt.w;
-            __syncthreads();
-            if (pos0 + (uint32_t)BLOCK < total) nxt = load(pos0 + (uint32_t)BLOCK + tid);   // in flight while this tile is consumed
-            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
-            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-            // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
-            // the tile up to a multiple of P past the last real one is real or pad, never stale
-            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) / P;
-            const float4* src = tile + 2u * g;
-            // one source pair {A, B} against this lane's target: d, r^2, then the weights (plain form, or the guarded one
-            // when the wave's vote says some lane is below the law's threshold) and the accumulation
-            struct Pair { f2 dx, dy, dz, r2, sm; };
-            auto geometry = [&](const float4 A, const float4 B) -> Pair {
-                Pair q;
-                q.sm = f2{B.z, B.w};
-                q.dx = f2{A.x, A.y} - ix2;
-                q.dy = f2{A.z, A.w} - iy2;
-                q.dz = (D == 3) ? f2{B.x, B.y} - iz2 : f2{0.f, 0.f};
-                q.r2 = q.dx * q.dx;
-                q.r2 = __builtin_elementwise_fma(q.dy, q.dy, q.r2);
-                if (D == 3) q.r2 = __builtin_elementwise_fma(q.dz, q.dz, q.r2);
-                return q;
-            };
-            auto special = [&](const Pair& q) -> unsigned long long {
-                return __builtin_amdgcn_ballot_w64(q.r2.x < law_special_below<LAW>()) | __builtin_amdgcn_ballot_w64(q.r2.y < law_special_below<LAW>());
-            };
-            auto guarded = [&](const Pair& q) -> f2 {
-                float ra = q.r2.x, rb = q.r2.y;
-                asm volatile("" : "+v"(ra), "+v"(rb));   // keeps the guarded form's compares in this (rare) branch: hipcc hoists them otherwise
-                return f2{leaf_weight<D, LAW>(ra, q.sm.x, q.dx.x, q.dy.x, q.dz.x), leaf_weight<D, LAW>(rb, q.sm.y, q.dx.y, q.dy.y, q.dz.y)};
-            };
-            auto plain = [&](const Pair& q) -> f2 {
-                f2 w = {__builtin_amdgcn_rcpf(q.r2.x), __builtin_amdgcn_rcpf(q.r2.y)};
-                w = w * w;
-                return w * q.sm;
-            };
-            auto add = [&](const Pair& q, const f2 w) {
-                ax = __builtin_elementwise_fma(w, q.dx, ax);
-                ay = __builtin_elementwise_fma(w, q.dy, ay);
-                if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
-            };
-            unsigned it = 0;
-            for (; it + 1u < trips; it += 2u, src += 4u * P) {   // two source pairs per trip: one vote, independent chains
-                const Pair q0 = geometry(src[0], src[1]), q1 = geometry(src[2u * P], src[2u * P + 1u]);
-                f2 w0, w1;
-                if (__builtin_expect((special(q0) | special(q1)) != 0ull, 0)) { w0 = guarded(q0); w1 = guarded(q1); }     // wave-uniform, rare
-                else { w0 = plain(q0); w1 = plain(q1); }
-                add(q0, w0);
-                add(q1, w1);
-            }
-            if (it < trips) {
-                const Pair q0 = geometry(src[0], src[1]);
-                const f2 w0 = __builtin_expect(special(q0) != 0ull, 0) ? guarded(q0) : plain(q0);
-                add(q0, w0);
-            }
-            pending += 2u * trips;
-            if (pending + (unsigned)BLOCK > 256u || pos0 + (uint32_t)BLOCK >= total) {   // workgroup-uniform
-                ox += (double)ax.x + (double)ax.y;
-                oy += (double)ay.x + (double)ay.y;
-                oz += (double)az.x + (double)az.y;
-                ax = ay = az = f2{0.f, 0.f};
-                pending = 0;
-            }
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)v_len, (int)e_next);
+            if (off_next >= len) { ++e_next; off_next = 0; continue; }   // empty leaves are stepped over here as well
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v_first, (int)e_next);
+            const uint32_t src_leaf = (uint32_t)__builtin_amdgcn_readlane((int)v_src, (int)e_next);
+            pc.n = (len - off_next < (uint32_t)kWave) ? (unsigned)(len - off_next) : (unsigned)kWave;
+            pc.own = src_leaf == tb.leaf;
+            if (lane < pc.n) pc.v = a.xm[first + off_next + lane];
+            off_next += pc.n;
+            return pc;
+        }
+    };
+    int cur = 0;
+    unsigned fill = 0;                                         // bodies staged in tile[cur] (+ overflow into tile[cur ^ 1])
+    bool own_cur = false, own_nxt = false;                     // the tile holds bodies of the target's own leaf
+    Piece p0 = issue(), p1 = issue();
+    while (p0.n) {
+        // piece p0 -> its tile slots (the part past the tile's end goes to the other buffer)
+        if (lane < p0.n) {
+            const unsigned q = fill + lane;
+            if (q < (unsigned)kLeafTile) tile[cur][slot_of(q)] = p0.v;
+            else tile[cur ^ 1][slot_of(q - (unsigned)kLeafTile)] = p0.v;
+        }
+        if (p0.own) { own_cur = own_cur || fill < (unsigned)kLeafTile; own_nxt = own_nxt || fill + p0.n > (unsigned)kLeafTile; }
+        fill += p0.n;
+        p0 = p1;
+        p1 = issue();
+        if (fill >= (unsigned)kLeafTile) {
+            consume(cur, (unsigned)kLeafTile, own_cur);
+            cur ^= 1; fill -= (unsigned)kLeafTile;
+            own_cur = own_nxt; own_nxt = false;
         }
     }
-    if (P > 1u) {                                              // block-uniform
+    if (fill) consume(cur, fill, own_cur);
+    flush();
+
+    // ---- the lane groups' sums meet, group order ----
+    if (G > 1u) {
         __syncthreads();
-        red[0][tid] = ox; red[1][tid] = oy; red[2][tid] = oz;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[k][lane] = o[k];
         __syncthreads();
-        if (g == 0u)
-            for (unsigned q = 1; q < P; ++q) { ox += red[0][q * W + t]; oy += red[1][q * W + t]; oz += red[2][q * W + t]; }
+        if (g_raw == 0u)
+            for (unsigned q = 1; q < G; ++q) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] += red[k][q * L + p];
+            }
     }
-    if (valid && g == 0u) {
-        a.acc[slot] = ox;
-        a.acc[(size_t)a.slots + slot] = oy;
-        if (D == 3) a.acc[2 * (size_t)a.slots + slot] = oz;
+    if (g_raw == 0u) {
+        const uint32_t s0 = tb.first + p;
+        a.acc[s0] = o[0];
+        a.acc[(size_t)a.slots + s0] = o[2];
+        if (D == 3) a.acc[2 * (size_t)a.slots + s0] = o[4];
+        if (has1) {
+            const uint32_t s1 = s0 + L;
+            a.acc[s1] = o[1];
+            a.acc[(size_t)a.slots + s1] = o[3];
+            if (D == 3) a.acc[2 * (size_t)a.slots + s1] = o[5];
+        }
     }
 }
 
@@ -279,11 +349,10 @@ __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restr
 }
 
 typedef void (*LeafKernel)(LeafArgs);
-template <int BLOCK>
 LeafKernel pick(int dim, int law) {
     static const LeafKernel table[2][3] = {
-        {leaf_pair_kernel<2, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, BLOCK>},
-        {leaf_pair_kernel<3, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, BLOCK>}};
+        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
     return table[dim - 2][law];
 }
 
@@ -344,30 +413,31 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
-    size_t nonempty = 0;
-    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
-    // block size by the mean leaf: up to 80 bodies per leaf one wave64 per block wastes fewer lanes than two
-    const uint32_t block = (nonempty && slots / nonempty <= 80) ? (uint32_t)kLeafBlockSmall : (uint32_t)kLeafBlock;
-    // Target blocks.  A block of c targets runs floor(block / c) lanes per target (kernel), so c just above block / 2 wastes
-    // almost half the lanes: such a piece is cut in two when that fills the lanes better by more than the cost of staging
-    // the source stream a second time (~15 %): 33..42 targets in a wave64 become two blocks at 3 lanes per target.
-    auto lane_use = [&](uint32_t c) -> double {
-        uint32_t lanes = block / c;
-        if (lanes > (uint32_t)kMaxLanesPerTarget) lanes = (uint32_t)kMaxLanesPerTarget;
-        return (double)(c * lanes) / (double)block;
+    // Target blocks: a leaf of c targets is cut into k pieces of ceil(c / k).  A piece of t targets runs G = min(64 / ceil(t/2),
+    // 16) lane groups, every lane making (sources / G) trips of 14 VALU, and stages the leaf's source list once (~0.3
+    // instructions per body): k is the one that minimises k x (14 / G + 0.3), e.g. 32 targets: one block at 4 groups;
+    // 34: two blocks of 17 at 7 groups instead of one at 3.
+    auto cost = [&](uint32_t piece) -> double {
+        const uint32_t lanes = (piece + 1) / 2;
+        uint32_t groups = (uint32_t)kWave / lanes;
+        if (groups > (uint32_t)kMaxGroups) groups = (uint32_t)kMaxGroups;
+        return 14.0 / (double)groups + 0.3;
     };
     std::vector<TargetBlock> blocks;
-    for (size_t l = 0; l < n_leaves; ++l)
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block) {
-            const uint32_t c = (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block;
-            const uint32_t half = (c + 1) / 2;
-            if (c >= 2 && lane_use(half) > 1.15 * lane_use(c)) {
-                blocks.push_back(TargetBlock{(uint32_t)l, f, half});
-                blocks.push_back(TargetBlock{(uint32_t)l, f + half, c - half});
-            } else {
-                blocks.push_back(TargetBlock{(uint32_t)l, f, c});
-            }
+    for (size_t l = 0; l < n_leaves; ++l) {
+        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
+        if (!c) continue;
+        const uint32_t k_min = (c + (uint32_t)kTargetsPerBlock - 1) / (uint32_t)kTargetsPerBlock;
+        uint32_t best_k = k_min;
+        double best = 1e300;
+        for (uint32_t k = k_min; k <= k_min + 7 && k <= c; ++k) {
+            const double v = (double)k * cost((c + k - 1) / k);
+            if (v < best - 1e-12) { best = v; best_k = k; }
         }
+        const uint32_t piece = (c + best_k - 1) / best_k;
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += piece)
+            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece});
+    }
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
@@ -408,8 +478,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     a.xm = xm; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
     a.blocks = d_blocks; a.acc = acc;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(block == (uint32_t)kLeafBlockSmall ? pick<kLeafBlockSmall>(dim, law) : pick<kLeafBlock>(dim, law),
-                       dim3((unsigned)blocks.size()), dim3(block), 0, d.stream, a);
+    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kWave), 0, d.stream, a);
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)

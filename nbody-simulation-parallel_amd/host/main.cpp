@@ -37,6 +37,10 @@ struct Options {
     double dt = 1.0;
     std::string init = "uniform";   // uniform | plummer
     std::string dump;               // prefix: write bodies and each method's forces as raw doubles
+    std::string load;               // --load <file>: raw Body<D> doubles (as --dump writes them) instead of generated bodies
+    int step_offset = 0;            // --step-offset k: the loaded state is step k of a run (labels of the energy log)
+    double e0 = 0.0;                // --e0 E: that run's initial energy (|dE/E0| keeps referring to it)
+    bool have_e0 = false;
     double G = ::G;                 // --G: coupling constant of the HIP stepping loop (default: the reference's)
     int energy_every = 0;           // --energy-every k: log E and |dE/E0| every k steps of the loop
     std::string integrator = "kd";  // --integrator kd|kdk: kick-drift as the reference helpers are ordered, or kick-drift-kick (extension)
@@ -45,10 +49,28 @@ struct Options {
     std::vector<int> devices;       // --gpus / --devices: shard the HIP rows over these GPUs (one process)
 };
 
+int g_exit_code = 0;   // 3: a self-check of the run failed (sharded row against the 1-GPU row)
+
 template <typename T>
 void dump_raw(const std::string& path, const std::vector<T>& v) {
     std::ofstream f(path, std::ios::binary);
     f.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(T)));
+}
+
+// The state a previous run dumped (fp64 positions, velocities, masses: Body<D> memory, body.h:8-11) back in: a run of k steps,
+// dumped, loaded and run k steps more equals one run of 2k steps bit for bit -- the device keeps its integrator state in fp64
+// and derives everything else from it (tests/test_gpu_harness.py).
+template <int D>
+std::vector<Body<D>> load_bodies(const std::string& path, int n) {
+    std::vector<Body<D>> bodies(static_cast<std::size_t>(n));
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f.is_open()) throw std::runtime_error("--load: cannot open " + path);
+    const std::streamsize want = static_cast<std::streamsize>(bodies.size() * sizeof(Body<D>));
+    if (f.tellg() != want) throw std::runtime_error("--load: " + path + " does not hold exactly N bodies of this dimension");
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(bodies.data()), want);
+    if (!f) throw std::runtime_error("--load: short read from " + path);
+    return bodies;
 }
 
 // tee to log file and stdout, as every message of the reference harness is
@@ -168,6 +190,31 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                     << 100.0 * pairs * 20.0 / kernel_s / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
                 if (distinct_devices < hip_ranks)
                     out << "  (" << hip_ranks << " ranks share " << distinct_devices << " device(s): the per-rank kernel time above is no per-GPU figure)" << std::endl;
+                if (hip_ranks > 1) {
+                    // the sharded row against the same evaluation on ONE GPU, on up to 1,024 evenly spaced bodies: the two differ
+                    // by the association of fp32 partial sums only (~1e-6); a stale or misplaced chunk would show as O(1)
+                    try {
+                        const Forces single = brute_force_hip_single_gpu<D>(bodies, opt.devices[0]);
+                        const int rows = std::min(n, 1024);
+                        double worst = 0.0;
+                        for (int r = 0; r < rows; ++r) {
+                            const std::size_t i = static_cast<std::size_t>((static_cast<long long>(r) * (n - 1)) / std::max(rows - 1, 1));
+                            double d2 = 0.0, f2 = 0.0;
+                            for (int k = 0; k < D; ++k) {
+                                d2 += (forces[i][k] - single[i][k]) * (forces[i][k] - single[i][k]);
+                                f2 += single[i][k] * single[i][k];
+                            }
+                            if (f2 > 0.0) worst = std::max(worst, std::sqrt(d2 / f2));
+                            else if (d2 > 0.0) worst = 1.0;
+                        }
+                        const bool ok = worst <= 1.0e-4;
+                        out << "Sharded-vs-single-GPU check (" << rows << " sampled rows of " << hip_label << " against the 1-GPU row): max |dF|/|F| = "
+                            << std::scientific << std::setprecision(3) << worst << std::fixed << std::setprecision(6) << (ok ? "  ok" : "  MISMATCH") << std::endl;
+                        if (!ok) g_exit_code = 3;
+                    } catch (const std::exception& e) {
+                        out << "Sharded-vs-single-GPU check: unavailable (" << e.what() << ")" << std::endl;
+                    }
+                }
                 hipcsv.open(base + "_hip.csv");
                 hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec,GPUs,DistinctDevices" << std::endl
                        << method.label << "," << n << "," << D << "," << std::fixed << std::setprecision(6) << seconds << ","
@@ -210,8 +257,10 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                 for (std::uint32_t e = lists.list_offsets[t]; e < lists.list_offsets[t + 1]; ++e)
                     pairs += static_cast<double>(lists.leaf_offsets[t + 1] - lists.leaf_offsets[t]) *
                              static_cast<double>(lists.leaf_offsets[lists.list_sources[e] + 1] - lists.leaf_offsets[lists.list_sources[e]]);
+            const double kernel_ms = last_leaf_pair_kernel_ms();
             out << "Time taken: " << seconds << " s  (" << lists.leaves() << " leaves, " << pairs << " pair terms, kernel "
-                << last_leaf_pair_kernel_ms() << " ms)" << std::endl;
+                << kernel_ms << " ms = " << pairs / (kernel_ms * 1e-3) << " pair terms/s, "
+                << 100.0 * pairs * 20.0 / (kernel_ms * 1e-3) / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
             print_validation_forces<D>(forces, n, log);
             print_validation_forces<D>(forces, n, std::cout);
             if (!opt.dump.empty()) dump_raw(opt.dump + "_NearField_HIP.f64", forces);
@@ -233,8 +282,10 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
             const int chunk = opt.energy_every > 0 ? opt.energy_every : opt.steps;
             if (opt.energy_every > 0) {
                 sim.energy(ke, pe);
-                e0 = ke + pe;
-                out << "step 0  E = " << std::setprecision(12) << e0 << "  (kinetic " << ke << ", potential " << pe << ")" << std::endl;
+                e0 = opt.have_e0 ? opt.e0 : ke + pe;   // a continued run keeps measuring against the energy it started with
+                out << "step " << opt.step_offset << "  E = " << std::setprecision(12) << ke + pe;
+                if (opt.have_e0) out << "  |dE/E0| = " << std::setprecision(3) << std::abs((ke + pe - e0) / e0) << std::setprecision(12);
+                out << "  (kinetic " << ke << ", potential " << pe << ")" << std::endl;
             }
             for (int done = 0; done < opt.steps;) {
                 const int k = std::min(chunk, opt.steps - done);
@@ -242,7 +293,7 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                 done += k;
                 if (opt.energy_every > 0) {
                     sim.energy(ke, pe);
-                    out << "step " << done << "  E = " << std::setprecision(12) << ke + pe << "  |dE/E0| = " << std::setprecision(3)
+                    out << "step " << opt.step_offset + done << "  E = " << std::setprecision(12) << ke + pe << "  |dE/E0| = " << std::setprecision(3)
                         << std::abs((ke + pe - e0) / e0) << std::setprecision(6) << "  (kinetic " << ke << ", potential " << pe
                         << ", 2K/|U| " << 2.0 * ke / std::abs(pe) << ")" << std::endl;
                 }
@@ -292,6 +343,8 @@ void usage(const char* argv0) {
               << "      --devices <list> Same with an explicit device list, e.g. 0,0,0 = three virtual ranks on GPU 0" << std::endl
               << "      --device-count  Print the number of HIP devices and exit" << std::endl
               << "      --dump <prefix> Write bodies and every method's forces as raw doubles (<prefix>_<Method>.f64)" << std::endl
+              << "      --load <file>   Read the N bodies from raw doubles (a <prefix>_Leapfrog_HIP.f64 or _bodies.f64 of --dump) instead of generating them" << std::endl
+              << "      --step-offset <k>, --e0 <E>  Continue a run: the loaded state is step k, |dE/E0| refers to E" << std::endl
               << "  -h, --help          Display this help message" << std::endl;
 }
 
@@ -369,6 +422,13 @@ int main(int argc, char* argv[]) {
             }
         } else if (arg == "--dump" && has_value) {
             opt.dump = argv[++i];
+        } else if (arg == "--load" && has_value) {
+            opt.load = argv[++i];
+        } else if (arg == "--step-offset" && has_value) {
+            opt.step_offset = std::stoi(argv[++i]);
+        } else if (arg == "--e0" && has_value) {
+            opt.e0 = std::stod(argv[++i]);
+            opt.have_e0 = true;
         } else if (arg == "--init" && has_value) {
             opt.init = argv[++i];
             if (opt.init != "uniform" && opt.init != "plummer") {
@@ -390,12 +450,14 @@ int main(int argc, char* argv[]) {
     const std::string run_id = get_run_id();
     try {
         if (opt.dimension == 2) {
-            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<2>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
-                                                : generate_random_bodies<2>(opt.num_bodies, opt.seed);
+            auto bodies = !opt.load.empty() ? load_bodies<2>(opt.load, opt.num_bodies)
+                          : opt.init == "plummer" ? generate_plummer_bodies<2>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
+                                                  : generate_random_bodies<2>(opt.num_bodies, opt.seed);
             run_benchmark<2>(bodies, run_id, opt);
         } else {
-            auto bodies = opt.init == "plummer" ? generate_plummer_bodies<3>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
-                                                : generate_random_bodies<3>(opt.num_bodies, opt.seed);
+            auto bodies = !opt.load.empty() ? load_bodies<3>(opt.load, opt.num_bodies)
+                          : opt.init == "plummer" ? generate_plummer_bodies<3>(opt.num_bodies, opt.seed, 1.0e5, 1.0e12, opt.law == "newton" ? opt.G : ::G)
+                                                  : generate_random_bodies<3>(opt.num_bodies, opt.seed);
             run_benchmark<3>(bodies, run_id, opt);
         }
     } catch (const std::exception& e) {
@@ -406,5 +468,5 @@ int main(int argc, char* argv[]) {
         return 1;
     }
     release_hip_caches();
-    return 0;
+    return g_exit_code;
 }

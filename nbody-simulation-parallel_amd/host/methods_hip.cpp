@@ -91,6 +91,15 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 }
 
 template <int D>
+std::vector<Vector<D>> brute_force_hip_single_gpu(const std::vector<Body<D>>& bodies, int device) {
+    std::vector<Vector<D>> forces(bodies.size());
+    const int rc = nbx_brute_force_forces(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G, device,
+                                          reinterpret_cast<double*>(forces.data()), nullptr);
+    if (rc != NBX_OK) raise("brute_force_hip_single_gpu", rc);
+    return forces;
+}
+
+template <int D>
 double brute_force_hip_accuracy(const std::vector<Body<D>>& bodies, const std::vector<Vector<D>>& reference) {
     if (reference.size() != bodies.size()) throw std::runtime_error("brute_force_hip_accuracy: reference size differs from the bodies");
     struct Ctx { nbx_ctx* h = nullptr; ~Ctx() { nbx_ctx_destroy(h); } } c;
@@ -178,6 +187,8 @@ template class HipSimulation<3>;
 // explicit instantiations, like nbody-sim-new/methods.cpp:452-499 does for the CPU solvers
 template std::vector<Vector<2>> brute_force_hip_n_body<2>(const std::vector<Body<2>>&);
 template std::vector<Vector<3>> brute_force_hip_n_body<3>(const std::vector<Body<3>>&);
+template std::vector<Vector<2>> brute_force_hip_single_gpu<2>(const std::vector<Body<2>>&, int);
+template std::vector<Vector<3>> brute_force_hip_single_gpu<3>(const std::vector<Body<3>>&, int);
 template double brute_force_hip_accuracy<2>(const std::vector<Body<2>>&, const std::vector<Vector<2>>&);
 template double brute_force_hip_accuracy<3>(const std::vector<Body<3>>&, const std::vector<Vector<3>>&);
 template void leapfrog_hip_n_body<2>(std::vector<Body<2>>&, double, int);

@@ -24,6 +24,11 @@
 template <int D>
 std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies);
 
+// The same evaluation on ONE GPU whatever set_hip_devices() says: the yardstick the harness holds a sharded row against
+// (sampled rows of BruteForce_HIP_x<G> vs this), so that a first run on a multi-GPU node proves more than delivery.
+template <int D>
+std::vector<Vector<D>> brute_force_hip_single_gpu(const std::vector<Body<D>>& bodies, int device);
+
 // nsteps x { forces; update_body_velocities(bodies, forces, dt); update_body_positions(bodies, dt); }
 // (methods.cpp:425-450) with the state resident on the device between steps.
 template <int D>

@@ -76,6 +76,41 @@ def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
     assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "sharded harness rows")
     state = np.fromfile(os.path.join(tmp_path, "d_Leapfrog_HIP.f64")).reshape(n, 7)
     assert np.allclose(state[:, :3], bodies[:, :3] + bodies[:, 3:6] * 6.0, rtol=1e-12, atol=0)
+    # the run checks itself: sampled rows of the sharded row against the same evaluation on one GPU
+    import re
+    m = re.search(r"Sharded-vs-single-GPU check \((\d+) sampled rows of BruteForce_HIP_x3 against the 1-GPU row\): max \|dF\|/\|F\| = ([0-9.eE+-]+)\s+ok", p.stdout)
+    assert m and int(m.group(1)) == 1024 and float(m.group(2)) < 1e-4, p.stdout[-1500:]
+
+
+def test_dump_and_load_continue_a_run_bit_for_bit(tmp_path):
+    """`--dump` / `--load`: k steps, the fp64 state written out, read back in by a second process and stepped k more times
+    equal 2k steps in one go BIT FOR BIT -- positions, velocities and masses (the device keeps its integrator state in fp64 and
+    derives the fp32 force inputs from it).  Strong coupling (G scaled so the forces bend the paths), Plummer sphere, and the
+    energy log of the continued run keeps referring to the first run's E0 (--e0, --step-offset)."""
+    import re
+    n, k = 16384, 6
+    common = ["-N", str(n), "-m", "g", "--init", "plummer", "--seed", "9", "--G", "1e3", "--dt", "1", "--energy-every", "3"]
+    one = _run(tmp_path, *common, "--steps", str(2 * k), "--dump", "full")
+    assert one.returncode == 0 and "Error executing" not in one.stderr, one.stderr
+    first = _run(tmp_path, *common, "--steps", str(k), "--dump", "half")
+    assert first.returncode == 0, first.stderr
+    e0 = re.search(r"step 0  E = ([0-9.eE+-]+)", first.stdout).group(1)
+    second = _run(tmp_path, *common, "--steps", str(k), "--load", "half_Leapfrog_HIP.f64", "--step-offset", str(k), "--e0", e0,
+                  "--dump", "cont")
+    assert second.returncode == 0 and "Error executing" not in second.stderr, second.stderr
+    a = np.fromfile(os.path.join(tmp_path, "full_Leapfrog_HIP.f64")).reshape(n, 7)
+    b = np.fromfile(os.path.join(tmp_path, "cont_Leapfrog_HIP.f64")).reshape(n, 7)
+    h = np.fromfile(os.path.join(tmp_path, "half_Leapfrog_HIP.f64")).reshape(n, 7)
+    start = np.fromfile(os.path.join(tmp_path, "full_bodies.f64")).reshape(n, 7)
+    assert np.abs(a[:, 3:6] - start[:, 3:6]).max() > 1e-3, "the coupling must matter"
+    assert not np.array_equal(h, a) and np.array_equal(a, b), "k + k steps through a dump/load must equal 2k steps bit for bit"
+    # the continued log carries on where the first stopped: same step labels, same energies, same reference energy
+    log_full = re.findall(r"step (\d+)  E = ([0-9.eE+-]+)  \|dE/E0\| = ([0-9.eE+-]+)", one.stdout)
+    log_cont = re.findall(r"step (\d+)  E = ([0-9.eE+-]+)  \|dE/E0\| = ([0-9.eE+-]+)", second.stdout)
+    assert [x for x in log_full if int(x[0]) >= k] == log_cont and len(log_cont) == 3, (log_full, log_cont)
+    # a file of the wrong size is refused
+    bad = _run(tmp_path, *common[:2], "-m", "g", "--load", "half_Leapfrog_HIP.f64", "-d", "2")
+    assert bad.returncode == 1 and "does not hold exactly N bodies" in bad.stderr
 
 
 def test_plummer_energy_logging(tmp_path):

@@ -22,4 +22,6 @@ for law, name in ((nbx.LAW_BRUTE, "brute"), (nbx.LAW_TREE_LEAF, "tree_leaf"), (n
         _, ms = nbx.leaf_pair_forces_hip(b, *leaves, law=law, return_kernel_ms=True)
         wall = min(wall, (time.perf_counter() - t0) * 1e3)
         best = min(best, ms)
-    print(f"law {name:9s}: kernel {best:.3f} ms = {pairs / best * 1e3:.3e} pairs/s;  whole call (validation, H2D, gather, kernel, scatter, D2H) {wall:.2f} ms", flush=True)
+    tflops = pairs * 20.0 / (best * 1e-3) / 1e12      # 20 flop per pair term, the brute-force path's convention
+    print(f"law {name:9s}: kernel {best:.3f} ms = {pairs / best * 1e3:.3e} pairs/s = {tflops:.1f} TFLOP/s = {tflops / 157.3:.3f} of the MI355X fp32 "
+          f"vector peak;  whole call (validation, H2D, gather, kernel, scatter, D2H) {wall:.2f} ms", flush=True)
