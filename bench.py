@@ -28,7 +28,7 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 FLOP_PER_INTERACTION = 20          # SURVEY 8d convention (3 sub, 5 r^2, rcp, 3 mul, 6 fma-acc, 2 guard)
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = FP32 matrix
 HBM_PEAK_GBPS = 8000.0
-PROFILE_ROUND = "r2"               # profiles/<round>/pmc_force_kernel.json: the committed PMC passes of this command
+PROFILE_ROUND = "r3"               # profiles/<round>/pmc_force_kernel.json: the committed PMC passes of this command
 
 
 def host_facts():
@@ -401,8 +401,9 @@ def main():
         # FETCH_SIZE under-reports coalesced streaming reads by 2 on gfx950 -- confirmed for THIS path's 4-/8-byte-per-lane
         # streams by the helper kernels of the same profile, whose byte counts are known exactly (classify_*: 12 B/body,
         # kick_drift: (12 S + 56) B/body read, 60 B/body written: "calibration" in the json, true/reported = 2.00 and 1.00).
-        kernel_of = {"fastpk_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1>", "fastpk1r_t8_w3_u4": "accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1>",
-                     "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>"}
+        qs = 1 if args.refine else 0   # mixed mode runs the build that also writes the spread sums
+        kernel_of = {"fastpk_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1, {qs}>", "fastpk1r_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1, {qs}>",
+                     "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>", "strict_f64_t4": "accel_f64_kernel<3, 4, 2, 2, 2, 0, 0>"}
         prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
         try:
             with open(os.path.join(ROOT, prof)) as f:

@@ -20,6 +20,7 @@
 #include "nbx_ctx.h"
 
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 using namespace nbx;
@@ -27,7 +28,7 @@ using namespace nbx;
 namespace {
 
 constexpr int kWave = 64;               // lanes per workgroup: one wave64
-constexpr int kTargetsPerBlock = 128;   // two targets per lane
+constexpr int kMaxTargetsPerLane = 4;    // a block holds up to 64 x 4 targets
 constexpr int kMaxGroups = 16;          // lane groups that split the sources of a block with few targets
 constexpr int kLeafTile = 64;               // source bodies per LDS tile
 constexpr int kLeafTileSlots = 96;          // float4 slots per tile buffer: groups x (padded) bodies per group <= 81
@@ -44,7 +45,8 @@ constexpr float kFar = 1.0e18f;                 // pad bodies: sources at +kFar,
 struct TargetBlock {
     uint32_t leaf;     // target leaf
     uint32_t first;    // first target slot (leaf order)
-    uint32_t count;    // <= kTargetsPerBlock
+    uint32_t count;    // <= 64 * tpl
+    uint32_t tpl;      // targets per lane: 2 or 4
 };
 
 struct LeafArgs {
@@ -90,159 +92,154 @@ __device__ __forceinline__ constexpr float law_special_below() {
     return LAW == NBX_LAW_BRUTE ? kR2SkipF : LAW == NBX_LAW_TREE_LEAF ? kTreeSkipF : kSmoothF;
 }
 
-// One wave64 = up to 128 targets of one leaf against that leaf's source list.
-//  * TWO TARGETS PER LANE as packed fp32 pairs (lane p holds targets p and p + L of the block, L = ceil(count / 2)), every
-//    source a broadcast: per source and lane 3 v_pk_add (d), v_pk_mul + 2 v_pk_fma (r^2), 2 v_rcp, 2 v_pk_mul (w^2, .m with
-//    the op_sel form of the brute-force kernel), 3 v_pk_fma (accumulate) and one v_min3 = 14 VALU per two pair terms.
-//  * A block of few targets (L <= 32 lanes) runs G = floor(64 / L) <= 16 LANE GROUPS that split the sources of every tile
-//    G ways; their fp64 sums meet in LDS at the end, in group order (deterministic).  The host cuts a leaf into the number
-//    of blocks that minimises (blocks) x (sources) x (14 / G + staging) -- e.g. 34 targets: two blocks of 17 at 7 groups
-//    instead of one at 3.
-//  * The tile is laid out GROUP-MAJOR in LDS (body q of the tile at slot (q mod G) * TGp + q / G, TGp odd): lane group g
-//    reads consecutive 16-byte slots with immediate offsets -- no address arithmetic in the pair loop, distinct groups on
-//    distinct banks -- one ds_read_b128 per source and lane, one conflict-free ds_write_b128 per staged body.
-//  * The source list is staged LEAF BY LEAF, not body by body: lane e holds list entry e (source leaf -> slot range), the
-//    wave walks the entries with v_readlane, and a leaf's bodies go from one 16-byte global load per lane straight to their
-//    tile slots; two leaves are in flight while a tile is consumed.  (Round 2 turned the list into a body stream by a
-//    prefix sum in LDS and searched the entry of every staged body: 24 % of its instructions.)
-//  * The law's special cases (skip / smoothing below ~1e-5 separation) and a body meeting itself cost nothing in the common
-//    path: the v_min3 keeps the smallest r^2 a lane saw in the tile; tiles that hold bodies of the target's own leaf, and
-//    any tile after which some lane's minimum lies below the law's threshold (the sums are then put back to what they
-//    were before the tile), go through the GUARDED loop -- a compare and select per pair term, and for the FMM law the
-//    smoothing branch behind a wave vote.
-template <int D, int LAW>
-__global__ __launch_bounds__(kWave) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[2][kLeafTileSlots];
-    __shared__ double red[6][kWave];
+// One wave64 = up to 64 x TPL targets of one leaf against that leaf's source list.
+//  * TPL = 2 or 4 TARGETS PER LANE as packed fp32 pairs (lane p holds targets p, p + L, ... of the block, L = ceil(count /
+//    TPL)), every source a broadcast: per source and target pair 3 v_pk_add (d), v_pk_mul + 2 v_pk_fma (r^2), 2 v_rcp,
+//    2 v_pk_mul (w^2, .m with the op_sel form of the brute-force kernel), 3 v_pk_fma (accumulate) and one v_min3 = 14 VALU
+//    per two pair terms.
+//  * A block of few targets runs G = floor(64 / L) <= 16 LANE GROUPS that split the sources of every tile G ways; their
+//    fp64 sums meet in LDS at the end, in group order (deterministic).  The host picks TPL and the number of blocks a leaf
+//    is cut into so that (blocks) x (sources) x (7 TPL / G + staging) is smallest.
+//  * The source list is staged LEAF BY LEAF: lane e holds list entry e (source leaf -> slot range), the wave walks the
+//    entries with v_readlane, and ONE SOURCE LEAF (a piece of up to 64 bodies of it) IS ONE TILE: one 16-byte global load
+//    per lane, issued two pieces ahead, one conflict-free ds_write_b128 into the lane's own slot.  No body stream, no
+//    prefix sum, no per-body search of the list (24 % of the instructions of round 2's kernel).
+//  * The tile is laid out GROUP-MAJOR in LDS (body q at slot (q mod G) * TGp + q / G, TGp odd): lane group g reads
+//    consecutive 16-byte slots with immediate offsets -- no address arithmetic in the pair loop, distinct groups on
+//    distinct banks -- one ds_read_b128 per source and lane.
+//  * The law's special cases (skip / smoothing below ~1e-5 separation) cost one v_min3 per two pair terms in the common
+//    path: it keeps the smallest r^2 a lane has seen.  Only the piece that is the target's own leaf (every body meets
+//    itself there) runs the GUARDED loop -- a compare and select per pair term, and for the FMM law the smoothing branch
+//    behind a wave vote.  If at the end some lane's minimum lies below the law's threshold -- two distinct bodies of
+//    different leaves closer than 3e-5: next to never -- the whole block is redone with the guarded loop throughout.
+template <int D, int LAW, int TPL>
+__device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock tb, float4 (&tile)[kLeafTileSlots], double (&red)[12][kWave]) {
+    constexpr int PAIRS = TPL / 2;
     const unsigned lane = threadIdx.x;
-    const TargetBlock tb = a.blocks[blockIdx.x];
     // ---- block geometry (wave-uniform) ----
     const unsigned c = tb.count;
-    const unsigned L = (c + 1u) >> 1;
+    const unsigned L = (c + (unsigned)TPL - 1u) / (unsigned)TPL;
     const unsigned fit = (unsigned)kWave / (L ? L : 1u);
     const unsigned G = fit < (unsigned)kMaxGroups ? fit : (unsigned)kMaxGroups;
     const unsigned TG = ((unsigned)kLeafTile + G - 1u) / G;
     const unsigned TGp = TG | 1u;                               // odd: lane groups land on distinct LDS banks
-    const unsigned inv_g = 65536u / G + 1u;                     // q / G = (q * inv_g) >> 16 for q < 128
     const unsigned p = lane % L, g_raw = lane / L;
-    const bool valid = g_raw < G;                               // lanes left over compute along with group 0, unused
-    const unsigned g = valid ? g_raw : 0u;
-    const bool has1 = p + L < c;
-    const float4 me0 = a.xm[tb.first + p];
-    const float4 me1 = has1 ? a.xm[tb.first + p + L] : make_float4(-kFar, -kFar, (D == 3) ? -kFar : 0.0f, 0.0f);
-    const f2 ix = {me0.x, me1.x}, iy = {me0.y, me1.y}, iz = {(D == 3) ? me0.z : 0.0f, (D == 3) ? me1.z : 0.0f};
-    double o[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};               // fp64 sums: x0 x1 y0 y1 z0 z1
-    f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};       // fp32 sums since the last flush
-    unsigned pending = 0;                                       // terms in them
+    const unsigned g = g_raw < G ? g_raw : 0u;                  // lanes left over compute along with group 0, unused
+    const unsigned slot_a = (lane % G) * TGp + lane / G;        // tile slot of body `lane` of a piece ...
+    const unsigned slot_b = ((lane + 64u) % G) * TGp + (lane + 64u) / G;   // ... and of the pad bodies 64 .. 64 + G - 1
+    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const unsigned t0 = p + (unsigned)(2 * q) * L, t1 = t0 + L;
+        const float4 far = make_float4(-kFar, -kFar, (D == 3) ? -kFar : 0.0f, 0.0f);   // pad target: every weight underflows to 0
+        const float4 m0 = t0 < c ? a.xm[tb.first + t0] : far, m1 = t1 < c ? a.xm[tb.first + t1] : far;
+        ix[q] = f2{m0.x, m1.x}; iy[q] = f2{m0.y, m1.y}; iz[q] = f2{(D == 3) ? m0.z : 0.0f, (D == 3) ? m1.z : 0.0f};
+    }
     const float4 pad = make_float4(kFar, kFar, (D == 3) ? kFar : 0.0f, 0.0f);
-    auto slot_of = [&](unsigned q) -> unsigned {                // body q of a tile -> its float4 slot
-        const unsigned qd = (q * inv_g) >> 16;
-        return (q - qd * G) * TGp + qd;
-    };
+    double o[3][TPL];                                           // fp64 sums [component][target of this lane]
+    f2 ax[PAIRS], ay[PAIRS], az[PAIRS];                         // fp32 sums since the last flush
+    unsigned pending;
+    float rmin;                                                 // smallest r^2 seen by the unguarded loop
 
-    // ---- the pair loops over one staged tile: `trips` sources per lane group ----
     auto flush = [&]() {
-        o[0] += (double)ax.x; o[1] += (double)ax.y; o[2] += (double)ay.x; o[3] += (double)ay.y;
-        if (D == 3) { o[4] += (double)az.x; o[5] += (double)az.y; }
-        ax = ay = az = f2{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            o[0][2 * q] += (double)ax[q].x; o[0][2 * q + 1] += (double)ax[q].y;
+            o[1][2 * q] += (double)ay[q].x; o[1][2 * q + 1] += (double)ay[q].y;
+            if (D == 3) { o[2][2 * q] += (double)az[q].x; o[2][2 * q + 1] += (double)az[q].y; }
+            ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
+        }
         pending = 0;
     };
-    auto fast4 = [&](const float4* __restrict__ src, float& rmin) {   // four sources, stage by stage (four independent chains)
-        f2 dx[4], dy[4], dz[4], r2[4], w[4], szm[4];
+    // NS sources against the lane's PAIRS target pairs, stage by stage (NS * PAIRS independent chains)
+    auto fast = [&](const float4* __restrict__ src, auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        f2 dx[NS][PAIRS], dy[NS][PAIRS], dz[NS][PAIRS], r2[NS][PAIRS], w[NS][PAIRS], szm[NS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 s = src[q];
-            szm[q] = f2{s.z, s.w};
-            dx[q] = f2{s.x, s.x} - ix;
-            dy[q] = f2{s.y, s.y} - iy;
-            dz[q] = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
+        for (int k = 0; k < NS; ++k) {
+            const float4 s = src[k];
+            szm[k] = f2{s.z, s.w};
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                dx[k][q] = f2{s.x, s.x} - ix[q];
+                dy[k][q] = f2{s.y, s.y} - iy[q];
+                dz[k][q] = (D == 3) ? f2{s.z, s.z} - iz[q] : f2{0.f, 0.f};
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r2[q] = dx[q] * dx[q];
+        for (int k = 0; k < NS; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r2[q] = __builtin_elementwise_fma(dy[q], dy[q], r2[q]);
+            for (int q = 0; q < PAIRS; ++q) r2[k][q] = dx[k][q] * dx[k][q];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) r2[k][q] = __builtin_elementwise_fma(dy[k][q], dy[k][q], r2[k][q]);
         if (D == 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r2[q] = __builtin_elementwise_fma(dz[q], dz[q], r2[q]);
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) r2[k][q] = __builtin_elementwise_fma(dz[k][q], dz[k][q], r2[k][q]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { w[q].x = __builtin_amdgcn_rcpf(r2[q].x); w[q].y = __builtin_amdgcn_rcpf(r2[q].y); }
+        for (int k = 0; k < NS; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rmin = __builtin_fminf(__builtin_fminf(rmin, r2[q].x), r2[q].y);   // v_min3_f32
+            for (int q = 0; q < PAIRS; ++q) { w[k][q].x = __builtin_amdgcn_rcpf(r2[k][q].x); w[k][q].y = __builtin_amdgcn_rcpf(r2[k][q].y); }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r2[q] = w[q] * w[q];
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) rmin = __builtin_fminf(__builtin_fminf(rmin, r2[k][q].x), r2[k][q].y);   // v_min3_f32
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) r2[k][q] = w[k][q] * w[k][q];
         // the mass is the HIGH half of the source's {z, m} register pair: op_sel spelled out (force_kernel.hip), applied to
         // w^2 (plain code, hazards handled by the compiler), never directly to a v_rcp result
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w[q]) : "v"(szm[q]), "v"(r2[q]));
+        for (int k = 0; k < NS; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ax = __builtin_elementwise_fma(w[q], dx[q], ax);
+            for (int q = 0; q < PAIRS; ++q) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w[k][q]) : "v"(szm[k]), "v"(r2[k][q]));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ay = __builtin_elementwise_fma(w[q], dy[q], ay);
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) ax[q] = __builtin_elementwise_fma(w[k][q], dx[k][q], ax[q]);
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) ay[q] = __builtin_elementwise_fma(w[k][q], dy[k][q], ay[q]);
         if (D == 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) az = __builtin_elementwise_fma(w[q], dz[q], az);
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) az[q] = __builtin_elementwise_fma(w[k][q], dz[k][q], az[q]);
         }
-    };
-    auto fast1 = [&](const float4 s, float& rmin) {
-        const f2 dx = f2{s.x, s.x} - ix, dy = f2{s.y, s.y} - iy, dz = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
-        f2 r2 = dx * dx;
-        r2 = __builtin_elementwise_fma(dy, dy, r2);
-        if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
-        rmin = __builtin_fminf(__builtin_fminf(rmin, r2.x), r2.y);
-        f2 w = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
-        w = w * w;
-        w = w * f2{s.w, s.w};
-        ax = __builtin_elementwise_fma(w, dx, ax);
-        ay = __builtin_elementwise_fma(w, dy, ay);
-        if (D == 3) az = __builtin_elementwise_fma(w, dz, az);
     };
     auto guarded1 = [&](const float4 s) {   // exact law per pair term: compare and select; FMM smoothing behind a wave vote
-        const f2 dx = f2{s.x, s.x} - ix, dy = f2{s.y, s.y} - iy, dz = (D == 3) ? f2{s.z, s.z} - iz : f2{0.f, 0.f};
-        f2 r2 = dx * dx;
-        r2 = __builtin_elementwise_fma(dy, dy, r2);
-        if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
-        f2 w;
         constexpr float T = law_special_below<LAW>();
-        if (LAW == NBX_LAW_FMM_P2P &&
-            (__builtin_amdgcn_ballot_w64(r2.x < T && r2.x > 0.0f) | __builtin_amdgcn_ballot_w64(r2.y < T && r2.y > 0.0f)) != 0ull) {
-            w = f2{leaf_weight<D, LAW>(r2.x, s.w, dx.x, dy.x, dz.x), leaf_weight<D, LAW>(r2.y, s.w, dx.y, dy.y, dz.y)};
-        } else {   // below the threshold: skipped (brute force, tree leaf), or the same position (FMM: r^2 = 0) -- weight 0
-            const f2 r2g = {(r2.x < T) ? __builtin_inff() : r2.x, (r2.y < T) ? __builtin_inff() : r2.y};
-            w = f2{__builtin_amdgcn_rcpf(r2g.x), __builtin_amdgcn_rcpf(r2g.y)};
-            w = w * w;
-            w = w * f2{s.w, s.w};
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const f2 dx = f2{s.x, s.x} - ix[q], dy = f2{s.y, s.y} - iy[q], dz = (D == 3) ? f2{s.z, s.z} - iz[q] : f2{0.f, 0.f};
+            f2 r2 = dx * dx;
+            r2 = __builtin_elementwise_fma(dy, dy, r2);
+            if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
+            f2 w;
+            if (LAW == NBX_LAW_FMM_P2P &&
+                (__builtin_amdgcn_ballot_w64(r2.x < T && r2.x > 0.0f) | __builtin_amdgcn_ballot_w64(r2.y < T && r2.y > 0.0f)) != 0ull) {
+                w = f2{leaf_weight<D, LAW>(r2.x, s.w, dx.x, dy.x, dz.x), leaf_weight<D, LAW>(r2.y, s.w, dx.y, dy.y, dz.y)};
+            } else {   // below the threshold: skipped (brute force, tree leaf), or the same position (FMM: r^2 = 0) -- weight 0
+                const f2 r2g = {(r2.x < T) ? __builtin_inff() : r2.x, (r2.y < T) ? __builtin_inff() : r2.y};
+                w = f2{__builtin_amdgcn_rcpf(r2g.x), __builtin_amdgcn_rcpf(r2g.y)};
+                w = w * w;
+                w = w * f2{s.w, s.w};
+            }
+            ax[q] = __builtin_elementwise_fma(w, dx, ax[q]);
+            ay[q] = __builtin_elementwise_fma(w, dy, ay[q]);
+            if (D == 3) az[q] = __builtin_elementwise_fma(w, dz, az[q]);
         }
-        ax = __builtin_elementwise_fma(w, dx, ax);
-        ay = __builtin_elementwise_fma(w, dy, ay);
-        if (D == 3) az = __builtin_elementwise_fma(w, dz, az);
-    };
-    auto consume = [&](int buf, unsigned cnt, bool own_leaf_inside) {   // all arguments wave-uniform
-        const unsigned trips = (cnt + G - 1u) / G;
-        if (lane < trips * G - cnt) tile[buf][slot_of(cnt + lane)] = pad;   // fill the last trip: massless bodies far away
-        __syncthreads();
-        if (pending + trips > 256u) flush();
-        const float4* __restrict__ src = &tile[buf][g * TGp];
-        bool guard = own_leaf_inside;
-        if (!guard) {
-            const f2 sx = ax, sy = ay, sz = az;
-            float rmin = __builtin_inff();
-            unsigned k = 0;
-            for (; k + 4u <= trips; k += 4u) fast4(src + k, rmin);
-            for (; k < trips; ++k) fast1(src[k], rmin);
-            guard = __builtin_amdgcn_ballot_w64(!(rmin >= law_special_below<LAW>())) != 0ull;   // a NaN r^2 also lands here
-            if (guard) { ax = sx; ay = sy; az = sz; }          // rare: this tile's terms are taken back and redone below
-        }
-        if (guard)
-            for (unsigned k = 0; k < trips; ++k) guarded1(src[k]);
-        pending += trips;
-        __syncthreads();                                       // the tile is free again
     };
 
     // ---- the source list, leaf by leaf ----
-    // (sub-)entries in flight: a leaf of more than 64 bodies is staged in pieces of 64
-    const uint32_t e_end = a.list_offsets[tb.leaf + 1];
-    uint32_t e_base = a.list_offsets[tb.leaf];                 // first list entry of the chunk held in the lanes
+    const uint32_t e_begin = a.list_offsets[tb.leaf], e_end = a.list_offsets[tb.leaf + 1];
+    uint32_t e_base = 0;                                       // first list entry of the chunk held in the lanes
     unsigned n_ent = 0, e_next = 0;                            // entries in the chunk, next one to issue
     uint32_t v_first = 0, v_len = 0, v_src = 0, off_next = 0;  // lane e: entry e_base + e
     auto load_chunk = [&]() {
@@ -255,14 +252,14 @@ __global__ __launch_bounds__(kWave) void leaf_pair_kernel(LeafArgs a) {
         }
         e_next = 0; off_next = 0;
     };
-    struct Piece { float4 v; unsigned n; bool own; };
-    auto issue = [&]() -> Piece {                              // wave-uniform control; the load stays in flight
-        Piece pc{pad, 0u, false};
+    // a piece = up to 64 bodies of one source leaf: (v, n, own) = this lane's body, the piece's size, "it is the target's leaf"
+    auto issue = [&](float4& v, unsigned& n, bool& own) {      // wave-uniform control; the load stays in flight
+        v = pad; n = 0u; own = false;
         for (;;) {
             if (e_next == n_ent) {
                 e_base += n_ent;
                 n_ent = e_next = 0;
-                if (e_base >= e_end) return pc;                // the list is exhausted: an empty piece, again and again
+                if (e_base >= e_end) return;                   // the list is exhausted: an empty piece, again and again
                 load_chunk();
                 continue;
             }
@@ -270,61 +267,97 @@ __global__ __launch_bounds__(kWave) void leaf_pair_kernel(LeafArgs a) {
             if (off_next >= len) { ++e_next; off_next = 0; continue; }   // empty leaves are stepped over here as well
             const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v_first, (int)e_next);
             const uint32_t src_leaf = (uint32_t)__builtin_amdgcn_readlane((int)v_src, (int)e_next);
-            pc.n = (len - off_next < (uint32_t)kWave) ? (unsigned)(len - off_next) : (unsigned)kWave;
-            pc.own = src_leaf == tb.leaf;
-            if (lane < pc.n) pc.v = a.xm[first + off_next + lane];
-            off_next += pc.n;
-            return pc;
+            n = (len - off_next < (uint32_t)kWave) ? (unsigned)(len - off_next) : (unsigned)kWave;
+            own = src_leaf == tb.leaf;
+            if (lane < n) v = a.xm[first + off_next + lane];
+            off_next += n;
+            return;
         }
     };
-    int cur = 0;
-    unsigned fill = 0;                                         // bodies staged in tile[cur] (+ overflow into tile[cur ^ 1])
-    bool own_cur = false, own_nxt = false;                     // the tile holds bodies of the target's own leaf
-    Piece p0 = issue(), p1 = issue();
-    while (p0.n) {
-        // piece p0 -> its tile slots (the part past the tile's end goes to the other buffer)
-        if (lane < p0.n) {
-            const unsigned q = fill + lane;
-            if (q < (unsigned)kLeafTile) tile[cur][slot_of(q)] = p0.v;
-            else tile[cur ^ 1][slot_of(q - (unsigned)kLeafTile)] = p0.v;
+    bool guard_all = false;
+    for (int pass = 0; pass < 2; ++pass) {                     // pass 1 only after a sub-threshold pair outside the own leaf
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) o[k][t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
+        pending = 0;
+        rmin = __builtin_inff();
+        e_base = e_begin; n_ent = e_next = 0; off_next = 0;
+        float4 v0, v1;
+        unsigned n0, n1;
+        bool own0, own1;
+        issue(v0, n0, own0);
+        issue(v1, n1, own1);
+        auto one_piece = [&](const float4 pv, const unsigned pn, const bool pown) {   // the piece is the tile: stage, then the pair loop
+            const unsigned trips = (pn + G - 1u) / G;
+            __syncthreads();                                   // the previous tile has been consumed
+            if (lane < pn) tile[slot_a] = pv;
+            else if (lane < trips * G) tile[slot_a] = pad;     // fill the last trip: massless bodies far away
+            if (trips * G > (unsigned)kWave && lane < trips * G - (unsigned)kWave) tile[slot_b] = pad;
+            __syncthreads();
+            if (pending + trips > 256u) flush();
+            const float4* __restrict__ src = &tile[g * TGp];
+            if (guard_all || pown) {
+                for (unsigned k = 0; k < trips; ++k) guarded1(src[k]);
+            } else {
+                constexpr int NS = (TPL == 2) ? 4 : 2;
+                unsigned k = 0;
+                for (; k + (unsigned)NS <= trips; k += (unsigned)NS) fast(src + k, std::integral_constant<int, NS>{});
+                for (; k < trips; ++k) fast(src + k, std::integral_constant<int, 1>{});
+            }
+            pending += trips;
+        };
+        while (n0) {                                           // two pieces per trip: their loads are issued two pieces ahead
+            one_piece(v0, n0, own0);
+            issue(v0, n0, own0);
+            if (!n1) break;
+            one_piece(v1, n1, own1);
+            issue(v1, n1, own1);
         }
-        if (p0.own) { own_cur = own_cur || fill < (unsigned)kLeafTile; own_nxt = own_nxt || fill + p0.n > (unsigned)kLeafTile; }
-        fill += p0.n;
-        p0 = p1;
-        p1 = issue();
-        if (fill >= (unsigned)kLeafTile) {
-            consume(cur, (unsigned)kLeafTile, own_cur);
-            cur ^= 1; fill -= (unsigned)kLeafTile;
-            own_cur = own_nxt; own_nxt = false;
-        }
+        flush();
+        if (guard_all || __builtin_amdgcn_ballot_w64(!(rmin >= law_special_below<LAW>())) == 0ull) break;   // a NaN r^2 also redoes
+        guard_all = true;
     }
-    if (fill) consume(cur, fill, own_cur);
-    flush();
 
     // ---- the lane groups' sums meet, group order ----
     if (G > 1u) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) red[k][lane] = o[k];
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) red[k * TPL + t][lane] = o[k][t];
         __syncthreads();
         if (g_raw == 0u)
             for (unsigned q = 1; q < G; ++q) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] += red[k][q * L + p];
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int t = 0; t < TPL; ++t) o[k][t] += red[k * TPL + t][q * L + p];
             }
     }
     if (g_raw == 0u) {
-        const uint32_t s0 = tb.first + p;
-        a.acc[s0] = o[0];
-        a.acc[(size_t)a.slots + s0] = o[2];
-        if (D == 3) a.acc[2 * (size_t)a.slots + s0] = o[4];
-        if (has1) {
-            const uint32_t s1 = s0 + L;
-            a.acc[s1] = o[1];
-            a.acc[(size_t)a.slots + s1] = o[3];
-            if (D == 3) a.acc[2 * (size_t)a.slots + s1] = o[5];
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+            const unsigned tt = p + (unsigned)t * L;
+            if (tt < c) {
+                const uint32_t s0 = tb.first + tt;
+                a.acc[s0] = o[0][t];
+                a.acc[(size_t)a.slots + s0] = o[1][t];
+                if (D == 3) a.acc[2 * (size_t)a.slots + s0] = o[2][t];
+            }
         }
     }
+}
+
+template <int D, int LAW>
+__global__ __launch_bounds__(kWave) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[kLeafTileSlots];
+    __shared__ double red[12][kWave];
+    const TargetBlock tb = a.blocks[blockIdx.x];
+    if (tb.tpl == 4u) leaf_block<D, LAW, 4>(a, tb, tile, red);   // wave-uniform
+    else leaf_block<D, LAW, 2>(a, tb, tile, red);
 }
 
 // staged Body<D> AoS fp64 (host order) -> leaf-ordered {x, y, z, m} fp32
@@ -413,30 +446,37 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
-    // Target blocks: a leaf of c targets is cut into k pieces of ceil(c / k).  A piece of t targets runs G = min(64 / ceil(t/2),
-    // 16) lane groups, every lane making (sources / G) trips of 14 VALU, and stages the leaf's source list once (~0.3
-    // instructions per body): k is the one that minimises k x (14 / G + 0.3), e.g. 32 targets: one block at 4 groups;
-    // 34: two blocks of 17 at 7 groups instead of one at 3.
-    auto cost = [&](uint32_t piece) -> double {
-        const uint32_t lanes = (piece + 1) / 2;
-        uint32_t groups = (uint32_t)kWave / lanes;
-        if (groups > (uint32_t)kMaxGroups) groups = (uint32_t)kMaxGroups;
-        return 14.0 / (double)groups + 0.3;
+    // Target blocks: a leaf of c targets is cut into k pieces of ceil(c / k), each run at 2 or 4 targets per lane.  A piece of
+    // t targets at TPL per lane runs G = min(64 / ceil(t / TPL), 16) lane groups, every lane making (sources / G) trips of
+    // 7 TPL VALU, and stages the leaf's source list once (about one instruction per two bodies, plus the block's fixed
+    // part): (k, TPL) minimise k x (sources x (7 TPL / G + 0.5) + 200).  32 targets: one block, 4 per lane, 8 groups;
+    // 34 targets: one block, 4 per lane, 7 groups (2 per lane would leave 3 groups).
+    auto groups_of = [&](uint32_t piece, uint32_t tpl) -> uint32_t {
+        const uint32_t lanes = (piece + tpl - 1) / tpl;
+        if (lanes > (uint32_t)kWave) return 0;
+        const uint32_t g = (uint32_t)kWave / lanes;
+        return g > (uint32_t)kMaxGroups ? (uint32_t)kMaxGroups : g;
     };
     std::vector<TargetBlock> blocks;
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (!c) continue;
-        const uint32_t k_min = (c + (uint32_t)kTargetsPerBlock - 1) / (uint32_t)kTargetsPerBlock;
-        uint32_t best_k = k_min;
+        double sources = 0.0;
+        for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e)
+            sources += (double)(leaf_offsets[list_sources[e] + 1] - leaf_offsets[list_sources[e]]);
+        const uint32_t k_min = (c + (uint32_t)(kWave * kMaxTargetsPerLane) - 1) / (uint32_t)(kWave * kMaxTargetsPerLane);
+        uint32_t best_k = k_min, best_tpl = 4;
         double best = 1e300;
-        for (uint32_t k = k_min; k <= k_min + 7 && k <= c; ++k) {
-            const double v = (double)k * cost((c + k - 1) / k);
-            if (v < best - 1e-12) { best = v; best_k = k; }
-        }
+        for (uint32_t k = k_min; k <= k_min + 3 && k <= c; ++k)
+            for (uint32_t tpl = 4; tpl >= 2; tpl -= 2) {       // ties go to 4 per lane: half the trips
+                const uint32_t g = groups_of((c + k - 1) / k, tpl);
+                if (!g) continue;
+                const double v = (double)k * (sources * (7.0 * tpl / g + 0.5) + 200.0);
+                if (v < best * (1.0 - 1e-9)) { best = v; best_k = k; best_tpl = tpl; }
+            }
         const uint32_t piece = (c + best_k - 1) / best_k;
         for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += piece)
-            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece});
+            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece, best_tpl});
     }
 
     NBX_HIP_TRY(hipSetDevice(device));

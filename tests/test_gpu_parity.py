@@ -347,6 +347,14 @@ def test_one_reciprocal_variant_extent_precondition(nbx, oracle):
             f = c.forces(oracle.G)
         assert np.isfinite(f).all()
         assert_force_parity(f, oracle.brute_force_seq(big), oracle.force_magnitude_sums(big), f"extent x{scale:g}")
+    # a NaN in the FIRST coordinate of a body (finite y, z after it): the pack pass's running maximum must keep the NaN, so
+    # the extent precondition fails and the two-reciprocal kernel is the one that runs ("a NaN sorts above everything")
+    nanb = oracle.round_inputs_to_f32(oracle.generate(79, n, dim))
+    nanb[100, 0] = float("nan")
+    with nbx.Context(n, dim) as c:
+        c.upload(nanb)
+        c.set_tuning(0, one)
+        assert c.effective_tuning()[0].startswith("fastpk_"), "a NaN coordinate must fail the extent precondition"
 
 
 @pytest.mark.parametrize("dim", (3, 2))

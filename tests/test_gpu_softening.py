@@ -76,6 +76,43 @@ def test_softened_energy_and_argument_checks(nbx, oracle):
             c.compute_accel()
         c.set_softening(1.0)
         c.compute_accel()
+    # ... and too LARGE a softening length is refused as well: every fp32 pair weight m / eps^4 would underflow and the call
+    # would return an all-zero field with status OK.  Masses <= 1e8: eps = 1e9 leaves 1e8 / 1e36 = 1e-28 (a normal fp32, just
+    # inside the bound); eps = 1e10 -> 1e-32: refused.  Under the Newtonian law the weight is m / eps^3.
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_softening(1.0e9)
+        c.compute_accel()
+        f = c.forces(oracle.G)
+        assert np.isfinite(f).all() and (np.abs(f).max(axis=1) > 0).all(), "forces at the accepted upper bound must not vanish"
+        c.set_softening(1.0e10)
+        with pytest.raises(nbx.NbxError) as e:
+            c.compute_accel()
+        assert e.value.status == 1 and "underflow" in str(e.value)
+        c.set_law(nbx.FORCE_LAW_NEWTON)                         # m / eps^3 = 1e8 / 1e30: representable again
+        c.compute_accel()
+        assert (np.abs(c.forces(oracle.G)).max(axis=1) > 0).all()
+
+
+def test_every_variant_with_softening_on(nbx, oracle):
+    """A caller's variant choice plus a softening length never ends in an opaque HIP error: variants without a softened
+    build (the exact and strict kernels, the A/B table entries) are replaced by the default fast kernel, for both laws."""
+    n, dim, eps = 2500, 3, 40.0
+    b = oracle.round_inputs_to_f32(oracle.generate(14, n, dim))
+    ref, S = oracle.force_rows_softened(b, eps)
+    refn, Sn = oracle.force_rows_softened(b, eps, newton=True)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.set_softening(eps)
+        for v, name in enumerate(nbx.variants()):
+            c.set_tuning(0, v)
+            assert c.effective_tuning()[0].startswith("fast"), (name, c.effective_tuning())
+            c.set_law(nbx.FORCE_LAW_REFERENCE)
+            c.compute_accel()
+            assert_force_parity(c.forces(oracle.G), ref, S, f"softened, asked for {name}")
+            c.set_law(nbx.FORCE_LAW_NEWTON)
+            c.compute_accel()
+            assert_force_parity(c.forces(oracle.G), refn, Sn, f"softened Newtonian, asked for {name}")
 
 
 def test_softened_plummer_sphere_conserves_energy_over_dynamical_times(nbx):
