@@ -42,12 +42,19 @@ static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double
               "fp32 thresholds must sit on the right side of the fp64 ones");
 constexpr float kFar = 1.0e18f;                 // pad bodies: sources at +kFar, pad targets at -kFar (r^2 ~ 1e37, weight underflows to 0)
 
-struct TargetBlock {
+struct TargetBlock {   // built on the host: a runtime integer division costs the GPU ~30 VALU, the kernel would need six per block
     uint32_t leaf;     // target leaf
     uint32_t first;    // first target slot (leaf order)
     uint32_t count;    // <= 64 * tpl
     uint32_t tpl;      // targets per lane: 2 or 4
+    uint32_t L;        // lanes per group = ceil(count / tpl)
+    uint32_t G;        // lane groups = min(64 / L, kMaxGroups)
+    uint32_t TGp;      // float4 slots per group in a tile: ceil(64 / G), made odd
+    uint32_t inv_L;    // q / L = (q * inv_L) >> 16 for q < 128  (inv = 65536 / d + 1)
+    uint32_t inv_G;
+    uint32_t pad_[3];
 };
+static_assert(sizeof(TargetBlock) == 48, "TargetBlock is read with scalar loads");
 
 struct LeafArgs {
     const float4* __restrict__ xm;     // [slots] leaf-ordered {x, y, z (0 in 2D), m}: one 16-byte load stages a body
@@ -116,17 +123,13 @@ template <int D, int LAW, int TPL>
 __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock tb, float4 (&tile)[kLeafTileSlots], double (&red)[12][kWave]) {
     constexpr int PAIRS = TPL / 2;
     const unsigned lane = threadIdx.x;
-    // ---- block geometry (wave-uniform) ----
-    const unsigned c = tb.count;
-    const unsigned L = (c + (unsigned)TPL - 1u) / (unsigned)TPL;
-    const unsigned fit = (unsigned)kWave / (L ? L : 1u);
-    const unsigned G = fit < (unsigned)kMaxGroups ? fit : (unsigned)kMaxGroups;
-    const unsigned TG = ((unsigned)kLeafTile + G - 1u) / G;
-    const unsigned TGp = TG | 1u;                               // odd: lane groups land on distinct LDS banks
-    const unsigned p = lane % L, g_raw = lane / L;
+    // ---- block geometry (wave-uniform, from the host's block table) ----
+    const unsigned c = tb.count, L = tb.L, G = tb.G, TGp = tb.TGp, inv_L = tb.inv_L, inv_G = tb.inv_G;
+    const unsigned g_raw = (lane * inv_L) >> 16, p = lane - g_raw * L;       // lane / L, lane % L
     const unsigned g = g_raw < G ? g_raw : 0u;                  // lanes left over compute along with group 0, unused
-    const unsigned slot_a = (lane % G) * TGp + lane / G;        // tile slot of body `lane` of a piece ...
-    const unsigned slot_b = ((lane + 64u) % G) * TGp + (lane + 64u) / G;   // ... and of the pad bodies 64 .. 64 + G - 1
+    const unsigned qa = (lane * inv_G) >> 16, qb = ((lane + 64u) * inv_G) >> 16;
+    const unsigned slot_a = (lane - qa * G) * TGp + qa;         // tile slot of body `lane` of a piece ...
+    const unsigned slot_b = (lane + 64u - qb * G) * TGp + qb;   // ... and of the pad bodies 64 .. 64 + G - 1
     f2 ix[PAIRS], iy[PAIRS], iz[PAIRS];
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
@@ -252,9 +255,11 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
         }
         e_next = 0; off_next = 0;
     };
-    // a piece = up to 64 bodies of one source leaf: (v, n, own) = this lane's body, the piece's size, "it is the target's leaf"
+    // a piece = up to 64 bodies of one source leaf: (v, n, own) = this lane's body, the piece's size, "it is the target's leaf".
+    // Lanes past the piece's end load its last body again (an address inside the leaf, no branch); the tile write gives them
+    // mass 0, so they pad the last trip: a massless copy of a real source contributes exactly 0.
     auto issue = [&](float4& v, unsigned& n, bool& own) {      // wave-uniform control; the load stays in flight
-        v = pad; n = 0u; own = false;
+        n = 0u; own = false;
         for (;;) {
             if (e_next == n_ent) {
                 e_base += n_ent;
@@ -269,7 +274,8 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
             const uint32_t src_leaf = (uint32_t)__builtin_amdgcn_readlane((int)v_src, (int)e_next);
             n = (len - off_next < (uint32_t)kWave) ? (unsigned)(len - off_next) : (unsigned)kWave;
             own = src_leaf == tb.leaf;
-            if (lane < n) v = a.xm[first + off_next + lane];
+            const float4* __restrict__ base = a.xm + (first + off_next);   // uniform: scalar base + per-lane 32-bit offset
+            v = base[lane < n ? lane : n - 1u];
             off_next += n;
             return;
         }
@@ -290,15 +296,14 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
         bool own0, own1;
         issue(v0, n0, own0);
         issue(v1, n1, own1);
+        const float4* __restrict__ src = &tile[g * TGp];      // this lane group's sources: consecutive slots
         auto one_piece = [&](const float4 pv, const unsigned pn, const bool pown) {   // the piece is the tile: stage, then the pair loop
-            const unsigned trips = (pn + G - 1u) / G;
+            const unsigned trips = ((pn + G - 1u) * inv_G) >> 16;
             __syncthreads();                                   // the previous tile has been consumed
-            if (lane < pn) tile[slot_a] = pv;
-            else if (lane < trips * G) tile[slot_a] = pad;     // fill the last trip: massless bodies far away
+            tile[slot_a] = make_float4(pv.x, pv.y, pv.z, lane < pn ? pv.w : 0.0f);
             if (trips * G > (unsigned)kWave && lane < trips * G - (unsigned)kWave) tile[slot_b] = pad;
             __syncthreads();
             if (pending + trips > 256u) flush();
-            const float4* __restrict__ src = &tile[g * TGp];
             if (guard_all || pown) {
                 for (unsigned k = 0; k < trips; ++k) guarded1(src[k]);
             } else {
@@ -324,17 +329,19 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
     // ---- the lane groups' sums meet, group order ----
     if (G > 1u) {
         __syncthreads();
+        double* const mine = &red[0][lane];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int t = 0; t < TPL; ++t) red[k * TPL + t][lane] = o[k][t];
+            for (int t = 0; t < TPL; ++t) mine[(k * TPL + t) * kWave] = o[k][t];
         __syncthreads();
         if (g_raw == 0u)
             for (unsigned q = 1; q < G; ++q) {
+                const double* const theirs = &red[0][q * L + p];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int t = 0; t < TPL; ++t) o[k][t] += red[k * TPL + t][q * L + p];
+                    for (int t = 0; t < TPL; ++t) o[k][t] += theirs[(k * TPL + t) * kWave];
             }
     }
     if (g_raw == 0u) {
@@ -475,8 +482,18 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
                 if (v < best * (1.0 - 1e-9)) { best = v; best_k = k; best_tpl = tpl; }
             }
         const uint32_t piece = (c + best_k - 1) / best_k;
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += piece)
-            blocks.push_back(TargetBlock{(uint32_t)l, f, (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece, best_tpl});
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += piece) {
+            TargetBlock tb = {};
+            tb.leaf = (uint32_t)l; tb.first = f; tb.count = (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece;
+            tb.tpl = best_tpl;
+            tb.L = (tb.count + best_tpl - 1) / best_tpl;
+            tb.G = groups_of(tb.count, best_tpl);
+            const uint32_t tg = ((uint32_t)kLeafTile + tb.G - 1) / tb.G;
+            tb.TGp = tg | 1u;
+            tb.inv_L = 65536u / tb.L + 1u;
+            tb.inv_G = 65536u / tb.G + 1u;
+            blocks.push_back(tb);
+        }
     }
 
     NBX_HIP_TRY(hipSetDevice(device));
