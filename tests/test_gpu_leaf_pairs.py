@@ -127,10 +127,10 @@ def test_ragged_structure_and_close_pairs(nbx, oracle):
 @pytest.mark.parametrize("dim", (3, 2))
 @pytest.mark.parametrize("big", (False, True))
 def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
-    """Target leaves of every size from 1 to 70, or 1 to 258 in steps of 3 (leaves beyond the 128 targets of a block), so that
-    every lane-group count, every split of a leaf into pieces and every partly filled last tile occurs; source lists of 1 to
-    300 entries with repeats and empty leaves in them (longer than the 64 list entries a wave holds: chunked), source leaves
-    beyond the 64 bodies of a tile (staged in pieces); all three laws."""
+    """Target leaves of every size from 1 to 70 (small: wave64 blocks) or 1 to 258 in steps of 3 (big: 128-lane blocks), so
+    that every lanes-per-target count, every split of a piece in two and every partly filled last tile occurs; source lists
+    of 1 to 300 entries with repeats and empty leaves in them (longer than one block of list entries: chunked), odd and even
+    stream lengths; all three laws."""
     sizes = list(range(1, 71)) if not big else list(range(1, 260, 3))
     sizes += [0, 0]                                                  # two empty leaves, also as sources
     rng = np.random.default_rng(90 + dim + 2 * big)
@@ -152,6 +152,7 @@ def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
     so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
     ss = np.concatenate(lists)
     leaves = (lo, lb, so, ss)
+    assert (np.mean([s for s in sizes if s]) > 80) == big           # which block size the library picks
     for law, name in LAWS:
         _check(nbx, oracle, b, leaves, law, f"every block shape, law {name}, D={dim}, big={big}")
 
