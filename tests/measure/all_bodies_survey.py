@@ -28,6 +28,8 @@ def main():
             b, label = o.round_inputs_to_f32(o.generate(2, 1 << 16, 3)), "uniform 3D N=65,536 (BASELINE config 2 input, seed 2)"
         elif w == "uniform20_2d":
             b, label = o.round_inputs_to_f32(o.generate(3, 1 << 20, 2)), "uniform 2D N=2^20 (seed 3)"
+        elif w == "uniform22":
+            b, label = o.round_inputs_to_f32(o.generate(6, 1 << 22, 3)), "uniform 3D N=2^22 (seed 6)"
         elif w == "plummer22":
             b = o.round_inputs_to_f32(nbx.plummer_bodies(1 << 22, 3, seed=5, a=1.0e5, total_mass=1.0e12))
             label = "Plummer N=2^22 (BASELINE config 5 input, seed 5)"
