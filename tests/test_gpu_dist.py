@@ -76,3 +76,29 @@ def test_two_ranks_one_gpu(tmp_path, oracle, world, n, dim):
     assert moved > 1e-6
     assert np.allclose(finals[0][:, d:2 * d], ref[:, d:2 * d], rtol=0, atol=3e-5 * moved)
     assert np.allclose(finals[0][:, :d], ref[:, :d], rtol=1e-9, atol=3e-5 * moved * dt * steps)
+
+
+def test_bench_line_for_two_ranks_carries_parity(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), rehearsed on the one
+    GPU with the gloo transport: the JSON line of an N > 1 run must prove correctness, not only delivery -- the exchange
+    self-check, sampled rows of the SHARDED evaluation against the oracle (here all rows: N <= 65,536), every body of every
+    shard against the strict fp64 kernel in default and mixed mode, and the CPU baseline beside it."""
+    import json
+    import subprocess
+    env = dict(os.environ, NBODY_BENCH_BACKEND="gloo", NBODY_BENCH_DEVICE="0", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--bodies", "32768"]
+    p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["exchange_check"]["mismatching_values"] == 0
+    a = r["accuracy"]
+    assert a["ranks"] == 2 and a["rows"] == 32768 and a["max_backward_err"] <= 1e-5
+    ab = a["all_bodies"]
+    assert ab["checked"] == 32768 and ab["yardstick_vs_oracle_rows"]["max_rel"] <= 1e-9
+    assert ab["default_fp32"]["max_backward"] <= 1e-5
+    assert ab["mixed_mode"]["n_over_1e-5"] == 0 and ab["mixed_mode"]["max_rel"] <= 1e-5
+    assert r["cpu_baseline"]["value"] > 0 and len(r["per_rank"]) == 2
