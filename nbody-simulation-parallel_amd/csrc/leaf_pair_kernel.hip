@@ -27,7 +27,8 @@ using namespace nbx;
 
 namespace {
 
-constexpr int kWave = 64;               // lanes per workgroup: one wave64
+constexpr int kWave = 64;               // lanes per block of targets: one wave64
+constexpr int kWavesPerGroup = 4;       // waves per workgroup, each with a target block of its own (no workgroup barrier)
 constexpr int kMaxTargetsPerLane = 4;    // a block holds up to 64 x 4 targets
 constexpr int kMaxGroups = 16;          // lane groups that split the sources of a block with few targets
 constexpr int kLeafTile = 64;               // source bodies per LDS tile
@@ -59,6 +60,7 @@ struct LeafArgs {
     const uint32_t* __restrict__ list_offsets;
     const uint32_t* __restrict__ list_sources;
     const TargetBlock* __restrict__ blocks;
+    uint32_t n_blocks;
     double* __restrict__ acc;          // [dim][slots]
 };
 
@@ -88,6 +90,14 @@ __device__ __forceinline__ float leaf_weight(float r2, float mj, float dx, float
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Ordering of a wave's own LDS traffic (its tile and its sums are private to it): the LDS executes one wave's accesses in
+// program order, so all that is needed is that the compiler keeps that order and waits for outstanding accesses.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Below this r^2 a pair leaves the plain m_j d / r^4 form under the law (skip or smoothing); leaf_weight decides how.
 template <int LAW>
@@ -121,7 +131,7 @@ template <int D, int LAW, int G>
 __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock tb, float4 (&tile)[2][kLeafTile], double (&red)[12][kWave]) {
     constexpr int PAIRS = 2, NS = 2;                           // target pairs per lane, sources per loop trip
     constexpr unsigned T = (unsigned)(NS * G * (kLeafTile / (NS * G)));   // bodies per tile: whole trips of NS * G
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x & (unsigned)(kWave - 1);
     const unsigned c = tb.count, L = tb.L;
     const unsigned g_raw = (lane * tb.inv_L) >> 16, p = lane - g_raw * L;   // lane / L, lane % L
     const unsigned g = g_raw < (unsigned)G ? g_raw : 0u;        // lanes left over compute along with group 0, unused
@@ -275,7 +285,7 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
     };
     bool guard_all = false;
     for (int pass = 0; pass < 2; ++pass) {                     // pass 1 only after a sub-threshold pair outside the own leaf
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < 12; ++k) mine[k * kWave] = 0.0;
 #pragma unroll
@@ -287,7 +297,7 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
         unsigned fill = 0;                                     // bodies staged in tile[cur], the overflow in tile[cur ^ 1]
         bool own_cur = false, own_nxt = false;                 // the tile holds bodies of the target's own leaf
         auto consume = [&](const int buf, const unsigned trips, const bool guard) {   // trips of NS * G bodies each
-            __syncthreads();                                   // the tile's writes have landed
+            wave_lds_sync();                                   // the tile's writes have landed
             if (pending + trips * (unsigned)NS > 256u) flush();
             const float4* __restrict__ src = &tile[buf][g];
             if (guard) {
@@ -298,7 +308,7 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
                 for (unsigned k = 0; k < trips; ++k) fast(src + k * (unsigned)(NS * G));   // one loop form for full and partial tiles
             }
             pending += trips * (unsigned)NS;
-            __syncthreads();                                   // the tile is free again
+            wave_lds_sync();                                   // the tile is free again
         };
         auto stage = [&](const float4 pv, const unsigned pn, const bool pown) {
             const unsigned q = fill + lane;
@@ -337,7 +347,7 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
     }
 
     // ---- the lane groups' sums meet, group order; every output written once ----
-    __syncthreads();
+    wave_lds_sync();
     if (g_raw == 0u) {
         double o[12];
 #pragma unroll
@@ -362,15 +372,20 @@ __device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock 
 }
 
 // Waves per SIMD the register allocation is held to: left alone (one wave64 per workgroup) the allocator spends 300+ VGPRs on
-// hoisted loads; 5 waves = at most 96 VGPRs.
+// hoisted loads; at 5 waves (96 VGPRs) it spills inside the pair loop, at 4 waves (120 used) it does not.
 #ifndef NBX_LEAF_WAVES
-#define NBX_LEAF_WAVES 5
+#define NBX_LEAF_WAVES 4
 #endif
 template <int D, int LAW>
-__global__ __launch_bounds__(kWave, NBX_LEAF_WAVES) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[2][kLeafTile];
-    __shared__ double red[12][kWave];
-    const TargetBlock tb = a.blocks[blockIdx.x];
+__global__ __launch_bounds__(kWave * kWavesPerGroup, NBX_LEAF_WAVES) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tiles[kWavesPerGroup][2][kLeafTile];
+    __shared__ double reds[kWavesPerGroup][12][kWave];
+    const unsigned wave = threadIdx.x / (unsigned)kWave;
+    const unsigned block = blockIdx.x * (unsigned)kWavesPerGroup + wave;   // wave-uniform
+    if (block >= a.n_blocks) return;
+    float4 (&tile)[2][kLeafTile] = tiles[wave];
+    double (&red)[12][kWave] = reds[wave];
+    const TargetBlock tb = a.blocks[__builtin_amdgcn_readfirstlane((int)block)];
     switch (tb.G) {   // wave-uniform; the lane-group count is a compile-time constant of the loop it selects
         case 1: leaf_block<D, LAW, 1>(a, tb, tile, red); break;
         case 2: leaf_block<D, LAW, 2>(a, tb, tile, red); break;
@@ -550,9 +565,9 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipGetLastError());
     LeafArgs a;
     a.xm = xm; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
-    a.blocks = d_blocks; a.acc = acc;
+    a.blocks = d_blocks; a.n_blocks = (uint32_t)blocks.size(); a.acc = acc;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kWave), 0, d.stream, a);
+    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)((blocks.size() + kWavesPerGroup - 1) / kWavesPerGroup)), dim3(kWave * kWavesPerGroup), 0, d.stream, a);
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
