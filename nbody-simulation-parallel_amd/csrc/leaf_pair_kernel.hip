@@ -8,30 +8,30 @@
 //
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
 // forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
-// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: ONE WAVE64 owns up to 128
-// targets of one leaf -- two per lane, held as packed fp32 pairs like the brute-force kernel's -- and that leaf's whole
-// source-leaf list, staged through LDS leaf by leaf; fp32 sums over at most 256 terms, flushed into fp64 accumulators.
-// No atomics, a fixed summation order, every output written once.  The comment at the kernel says how the lanes share
-// the work.  Leaves are small (the reference caps them at 100 bodies, methods.h:26), so the launch is tens of thousands
-// of short single-wave workgroups; HBM traffic is 16 B per (target block, source body), served mostly from L2.
-// VALU-issue-bound: 14 VALU per source and lane (= per two pair terms), ~12 % on top for staging, flushes and the
-// prologue (round 2's kernel: 16 per two terms, 24 % on top, 4-way LDS bank conflicts on its tile writes).
+// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: one workgroup (one wave64 when the mean
+// leaf holds <= 80 bodies, else two) owns up to 64 (128) targets of ONE leaf and walks that leaf's source-leaf list as one
+// stream of bodies staged through LDS in tiles of one body per lane {x,y,z,m}; fp32 sums per tile, flushed into fp64
+// second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
+// once.  The comment at the kernel says how the lanes share the work.  Leaves are small (the reference caps them at 100
+// bodies, methods.h:26), so the launch is tens of thousands of short workgroups; HBM traffic is 16 B per (target block,
+// source body) served mostly from L2.  VALU-issue-bound (counters: profiles/r2/pmc_leaf_pair_kernel.txt): 76 % of the
+// instructions are the pair loop, the rest stages tiles and flushes sums; tiles of 256 bodies instead of 64, or half the
+// LDS reads, changed nothing measurable.
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 
 #include <cstdio>
-#include <type_traits>
 #include <vector>
 
 using namespace nbx;
 
 namespace {
 
-constexpr int kWave = 64;               // lanes per block of targets: one wave64
-constexpr int kWavesPerGroup = 4;       // waves per workgroup, each with a target block of its own (no workgroup barrier)
-constexpr int kMaxTargetsPerLane = 4;    // a block holds up to 64 x 4 targets
-constexpr int kMaxGroups = 16;          // lane groups that split the sources of a block with few targets
-constexpr int kLeafTile = 64;               // source bodies per LDS tile
+// targets per workgroup = source bodies per LDS tile: 128 lanes (two wave64), or one wave64 when the leaves are small
+// (the mean leaf of the reference's trees is well under 100 bodies, methods.h:26) so that fewer lanes idle
+constexpr int kLeafBlock = 128;
+constexpr int kLeafBlockSmall = 64;
+constexpr int kMaxLanesPerTarget = 8;   // a block of few targets gives each up to this many lanes (they split the sources)
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
 constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
@@ -40,18 +40,12 @@ constexpr float kNormZeroF = 0x1.79ca12p-67f;   // 1.00000005e-20 (vector.h:93-9
 constexpr float kSameF = 1.0e-14f;              // largest fp32 <= 1e-14 (fmm_parlay.cpp:995-1000: |d_k| > 1e-14 -> distinct)
 static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double)kNormZeroF >= 1e-20 && (double)kSameF <= 1e-14,
               "fp32 thresholds must sit on the right side of the fp64 ones");
-constexpr float kFar = 1.0e18f;                 // pad bodies: sources at +kFar, pad targets at -kFar (r^2 ~ 1e37, weight underflows to 0)
 
-struct TargetBlock {   // built on the host: a runtime integer division costs the GPU ~30 VALU, the kernel would need six per block
+struct TargetBlock {
     uint32_t leaf;     // target leaf
     uint32_t first;    // first target slot (leaf order)
-    uint32_t count;    // <= 256: four targets per lane
-    uint32_t L;        // lanes per group = ceil(count / 4)
-    uint32_t G;        // lane groups: the largest of {1..10, 12, 16} that fits 64 / L
-    uint32_t inv_L;    // q / L = (q * inv_L) >> 16 for q < 128  (inv = 65536 / L + 1)
-    uint32_t pad_[2];
+    uint32_t count;    // <= the launch's block size
 };
-static_assert(sizeof(TargetBlock) == 32, "TargetBlock is read with scalar loads");
 
 struct LeafArgs {
     const float4* __restrict__ xm;     // [slots] leaf-ordered {x, y, z (0 in 2D), m}: one 16-byte load stages a body
@@ -60,7 +54,6 @@ struct LeafArgs {
     const uint32_t* __restrict__ list_offsets;
     const uint32_t* __restrict__ list_sources;
     const TargetBlock* __restrict__ blocks;
-    uint32_t n_blocks;
     double* __restrict__ acc;          // [dim][slots]
 };
 
@@ -91,314 +84,176 @@ __device__ __forceinline__ float leaf_weight(float r2, float mj, float dx, float
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Ordering of a wave's own LDS traffic (its tile and its sums are private to it): the LDS executes one wave's accesses in
-// program order, so all that is needed is that the compiler keeps that order and waits for outstanding accesses.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Below this r^2 a pair leaves the plain m_j d / r^4 form under the law (skip or smoothing); leaf_weight decides how.
 template <int LAW>
 __device__ __forceinline__ constexpr float law_special_below() {
     return LAW == NBX_LAW_BRUTE ? kR2SkipF : LAW == NBX_LAW_TREE_LEAF ? kTreeSkipF : kSmoothF;
 }
 
-// One wave64 = up to 256 targets of one leaf against that leaf's source list.
-//  * FOUR TARGETS PER LANE as two packed fp32 pairs (lane p holds targets p, p + L, p + 2L, p + 3L of the block, L = ceil(count /
-//    4)), every source a broadcast: per source and target pair 3 v_pk_add (d), v_pk_mul + 2 v_pk_fma (r^2), 2 v_rcp,
-//    2 v_pk_mul (w^2, .m with the op_sel form of the brute-force kernel), 3 v_pk_fma (accumulate) and one v_min3 = 14 VALU
-//    per two pair terms.
-//  * A block runs G = floor(64 / L) <= 16 LANE GROUPS that split the sources G ways (group g takes bodies g, g + G, ... of
-//    the stream); their sums meet in LDS at the end, in group order (deterministic).  G IS A TEMPLATE PARAMETER (the kernel
-//    switches on the block's value once): the stride between a group's sources, the tile length T = 2 G floor(64 / 2G) and
-//    every LDS offset of the pair loop are compile-time constants -- no address arithmetic in the loop, one loop form
-//    for full and partial tiles (the stream's end is padded to a whole trip of 2 G massless bodies), no remainder loop.
-//  * The source list is staged LEAF BY LEAF into a body STREAM in natural order: lane e holds list entry e (source leaf ->
-//    slot range), the wave walks the entries with v_readlane, one 16-byte global load per lane (issued two pieces ahead)
-//    and one ds_write_b128 put up to T bodies of a leaf behind the bodies already staged; T staged bodies are one tile.
-//    No prefix sum, no per-body search of the list.
-//  * fp32 sums per lane (a lane sees sources / G terms: 108 at 864 sources and 8 groups), flushed into fp64 sums that live
-//    in LDS (the reduction buffer itself) whenever 256 terms are reached -- no fp64 accumulator occupies a register during
-//    the pair loop.
-//  * The law's special cases (skip / smoothing below ~1e-5 separation) cost one v_min3 per two pair terms in the common
-//    path: it keeps the smallest r^2 a lane has seen.  Tiles that hold bodies of the target's own leaf (every body meets
-//    itself there) run the GUARDED loop -- a compare and select per pair term, and for the FMM law the smoothing branch
-//    behind a wave vote.  If at the end some lane's minimum lies below the law's threshold -- two distinct bodies of
-//    different leaves closer than 3e-5: next to never -- the whole block is redone with the guarded loop throughout.
-template <int D, int LAW, int G>
-__device__ __forceinline__ void leaf_block(const LeafArgs& a, const TargetBlock tb, float4 (&tile)[2][kLeafTile], double (&red)[12][kWave]) {
-    constexpr int PAIRS = 2, NS = 2;                           // target pairs per lane, sources per loop trip
-    constexpr unsigned T = (unsigned)(NS * G * (kLeafTile / (NS * G)));   // bodies per tile: whole trips of NS * G
-    const unsigned lane = threadIdx.x & (unsigned)(kWave - 1);
-    const unsigned c = tb.count, L = tb.L;
-    const unsigned g_raw = (lane * tb.inv_L) >> 16, p = lane - g_raw * L;   // lane / L, lane % L
-    const unsigned g = g_raw < (unsigned)G ? g_raw : 0u;        // lanes left over compute along with group 0, unused
-    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS];
-#pragma unroll
-    for (int q = 0; q < PAIRS; ++q) {
-        const unsigned t0 = p + (unsigned)(2 * q) * L, t1 = t0 + L;
-        const float4 far = make_float4(-kFar, -kFar, (D == 3) ? -kFar : 0.0f, 0.0f);   // pad target: every weight underflows to 0
-        const float4 m0 = t0 < c ? a.xm[tb.first + t0] : far, m1 = t1 < c ? a.xm[tb.first + t1] : far;
-        ix[q] = f2{m0.x, m1.x}; iy[q] = f2{m0.y, m1.y}; iz[q] = f2{(D == 3) ? m0.z : 0.0f, (D == 3) ? m1.z : 0.0f};
-    }
-    const float4 pad = make_float4(kFar, kFar, (D == 3) ? kFar : 0.0f, 0.0f);
-    f2 ax[PAIRS], ay[PAIRS], az[PAIRS];                         // fp32 sums since the last flush
-    unsigned pending;                                           // terms in them
-    float rmin;                                                 // smallest r^2 seen by the unguarded loop
-    double* const mine = &red[0][lane];                         // this lane's fp64 sums: [component * 4 + target][lane]
-
-    auto flush = [&]() {
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-            mine[(0 * 4 + 2 * q) * kWave] += (double)ax[q].x; mine[(0 * 4 + 2 * q + 1) * kWave] += (double)ax[q].y;
-            mine[(1 * 4 + 2 * q) * kWave] += (double)ay[q].x; mine[(1 * 4 + 2 * q + 1) * kWave] += (double)ay[q].y;
-            if (D == 3) { mine[(2 * 4 + 2 * q) * kWave] += (double)az[q].x; mine[(2 * 4 + 2 * q + 1) * kWave] += (double)az[q].y; }
-            ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
+// One workgroup = up to BLOCK targets of one leaf against that leaf's source list.
+//  * The list is read ONCE, by the lanes in parallel (lane k: list entry k -> that source leaf's slot range), and turned
+//    into one stream of source bodies by a prefix sum over the leaf sizes in LDS; tiles are then cut from the STREAM
+//    (BLOCK consecutive stream positions, whatever leaves they fall in), not from single leaves.  Walking the list leaf
+//    by leaf cost a chain of three dependent loads per ~30-body tile and left half of every tile empty.
+//  * Two SOURCES per lane and iteration, as packed fp32 pairs (v_pk_add/fma/mul_f32: 3 + 3 + 2 + 3 packed instructions and
+//    two v_rcp_f32 for two pairs, where one source at a time took 12 scalar ones and a v_rcp per pair).  The tile is
+//    staged in LDS as source PAIRS {xa,xb,ya,yb},{za,zb,ma,mb}, so each ds_read_b128 lands in aligned register pairs.
+//  * The law's special cases (skip / smoothing below ~1e-5 separation, and a body meeting itself in its own leaf) are
+//    rare: one v_cmp per pair and a wave-wide vote; only a wave in which some lane sees r^2 below the law's threshold
+//    takes the guarded scalar weights (leaf_weight) for that source pair -- which is every pair of the target's own leaf
+//    (each source there is some lane's own body) and next to nothing else.
+//  * Leaves are small (the reference caps them at 100 bodies; a uniform grid at 32 per leaf leaves half of a wave64 idle
+//    with one lane per target): a block whose targets fill at most half / a quarter of the lanes gives each target 2 / 4
+//    lanes, which split the source pairs of every tile between them; their fp64 sums meet in LDS at the end, in lane
+//    group order (deterministic).
+template <int D, int LAW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[BLOCK + 2 * kMaxLanesPerTarget];   // BLOCK/2 source pairs x 2 float4, + pad pairs past the end
+    __shared__ double red[3][BLOCK];
+    __shared__ uint32_t seg_end[BLOCK];     // stream position one past the last body of list entry k (inclusive prefix sum)
+    __shared__ uint32_t seg_first[BLOCK];   // slot of stream position 0 if entry k started there: slot = seg_first[k] + position
+    const unsigned tid = threadIdx.x;
+    const TargetBlock tb = a.blocks[blockIdx.x];
+    // lanes per target: as many whole groups of `count` lanes as the block holds (21 targets in a wave64: 3 lanes each)
+    const unsigned W = tb.count ? tb.count : 1u;
+    const unsigned fit = (unsigned)BLOCK / W;
+    const unsigned P = fit < (unsigned)kMaxLanesPerTarget ? fit : (unsigned)kMaxLanesPerTarget;
+    const unsigned t = tid % W, g_raw = tid / W;
+    const bool valid = g_raw < P;                              // lanes left over compute along with group 0, unused
+    const unsigned g = valid ? g_raw : 0u;
+    const uint32_t slot = tb.first + (valid ? t : 0u);
+    const float4 me = a.xm[slot];
+    const float ix = me.x, iy = me.y, iz = (D == 3) ? me.z : 0.0f;
+    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    float* const tf = reinterpret_cast<float*>(tile);
+    const unsigned wr = (tid >> 1) * 8u + (tid & 1u);      // source tid = half (tid & 1) of pair tid / 2
+    // the lane groups stride through the tile's pairs P at a time: the last trip may reach up to P - 1 pairs past the
+    // tile -- massless bodies far away, staged once
+    if (tid < 2u * (unsigned)kMaxLanesPerTarget)
+        tile[BLOCK + tid] = (tid & 1u) ? make_float4((D == 3) ? 1.0e18f : 0.0f, (D == 3) ? 1.0e18f : 0.0f, 0.f, 0.f) : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 1.0e18f);
+    const uint32_t e1 = a.list_offsets[tb.leaf + 1];
+    // the list in chunks of BLOCK entries (one chunk for every list the reference's trees produce); all workgroup-uniform
+    for (uint32_t e0 = a.list_offsets[tb.leaf]; e0 < e1; e0 += (uint32_t)BLOCK) {
+        const unsigned n_ent = (e1 - e0 < (uint32_t)BLOCK) ? (unsigned)(e1 - e0) : (unsigned)BLOCK;
+        uint32_t first = 0, len = 0;
+        if (tid < n_ent) {
+            const uint32_t s = a.list_sources[e0 + tid];
+            first = a.leaf_offsets[s];
+            len = a.leaf_offsets[s + 1] - first;
         }
-        pending = 0;
-    };
-    // NS sources (this group's: G slots apart) against the lane's PAIRS target pairs, stage by stage: NS * PAIRS chains
-    auto fast = [&](const float4* __restrict__ src) {
-        f2 dx[NS][PAIRS], dy[NS][PAIRS], dz[NS][PAIRS], r2[NS][PAIRS], w[NS][PAIRS], szm[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const float4 s = src[k * G];
-            szm[k] = f2{s.z, s.w};
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                dx[k][q] = f2{s.x, s.x} - ix[q];
-                dy[k][q] = f2{s.y, s.y} - iy[q];
-                dz[k][q] = (D == 3) ? f2{s.z, s.z} - iz[q] : f2{0.f, 0.f};
+        __syncthreads();                                   // the previous chunk's last tile and tables are done with
+        seg_end[tid] = len;
+        __syncthreads();
+        for (unsigned d = 1; d < (unsigned)BLOCK; d <<= 1) {   // inclusive prefix sum (Hillis-Steele)
+            const uint32_t add = (tid >= d) ? seg_end[tid - d] : 0u;
+            __syncthreads();
+            seg_end[tid] += add;
+            __syncthreads();
+        }
+        const uint32_t my_end = seg_end[tid];
+        seg_first[tid] = first - (my_end - len);
+        __syncthreads();
+        const uint32_t total = seg_end[BLOCK - 1];         // bodies in this chunk's stream
+        // Tiles of the stream, software-pipelined: the next tile's global loads are issued before the current tile is
+        // consumed, so their latency hides behind the pair loop.
+        unsigned k = 0;                                    // this lane's list entry; only ever moves forward
+        auto load = [&](uint32_t pos) -> float4 {
+            // positions past the stream's end stage a massless body far away: it pads the last tile to whole pairs and
+            // contributes exactly 0 under every law (r^2 ~ 1e36 is finite in fp32, w = 0 * r^-4)
+            float4 v = make_float4(1.0e18f, 1.0e18f, (D == 3) ? 1.0e18f : 0.0f, 0.f);
+            if (pos < total) {
+                while (pos >= seg_end[k]) ++k;             // empty leaves are stepped over here as well
+                const uint32_t j = seg_first[k] + pos;
+                v = a.xm[j];
             }
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) r2[k][q] = dx[k][q] * dx[k][q];
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) r2[k][q] = __builtin_elementwise_fma(dy[k][q], dy[k][q], r2[k][q]);
-        if (D == 3) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-#pragma unroll
-                for (int q = 0; q < PAIRS; ++q) r2[k][q] = __builtin_elementwise_fma(dz[k][q], dz[k][q], r2[k][q]);
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) { w[k][q].x = __builtin_amdgcn_rcpf(r2[k][q].x); w[k][q].y = __builtin_amdgcn_rcpf(r2[k][q].y); }
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) rmin = __builtin_fminf(__builtin_fminf(rmin, r2[k][q].x), r2[k][q].y);   // v_min3_f32
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) r2[k][q] = w[k][q] * w[k][q];
-        // the mass is the HIGH half of the source's {z, m} register pair: op_sel spelled out (force_kernel.hip), applied to
-        // w^2 (plain code, hazards handled by the compiler), never directly to a v_rcp result
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w[k][q]) : "v"(szm[k]), "v"(r2[k][q]));
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) ax[q] = __builtin_elementwise_fma(w[k][q], dx[k][q], ax[q]);
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) ay[q] = __builtin_elementwise_fma(w[k][q], dy[k][q], ay[q]);
-        if (D == 3) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-#pragma unroll
-                for (int q = 0; q < PAIRS; ++q) az[q] = __builtin_elementwise_fma(w[k][q], dz[k][q], az[q]);
-        }
-    };
-    auto guarded1 = [&](const float4 s) {   // exact law per pair term: compare and select; FMM smoothing behind a wave vote
-        constexpr float TH = law_special_below<LAW>();
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-            const f2 dx = f2{s.x, s.x} - ix[q], dy = f2{s.y, s.y} - iy[q], dz = (D == 3) ? f2{s.z, s.z} - iz[q] : f2{0.f, 0.f};
-            f2 r2 = dx * dx;
-            r2 = __builtin_elementwise_fma(dy, dy, r2);
-            if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
-            f2 w;
-            if (LAW == NBX_LAW_FMM_P2P &&
-                (__builtin_amdgcn_ballot_w64(r2.x < TH && r2.x > 0.0f) | __builtin_amdgcn_ballot_w64(r2.y < TH && r2.y > 0.0f)) != 0ull) {
-                w = f2{leaf_weight<D, LAW>(r2.x, s.w, dx.x, dy.x, dz.x), leaf_weight<D, LAW>(r2.y, s.w, dx.y, dy.y, dz.y)};
-            } else {   // below the threshold: skipped (brute force, tree leaf), or the same position (FMM: r^2 = 0) -- weight 0
-                const f2 r2g = {(r2.x < TH) ? __builtin_inff() : r2.x, (r2.y < TH) ? __builtin_inff() : r2.y};
-                w = f2{__builtin_amdgcn_rcpf(r2g.x), __builtin_amdgcn_rcpf(r2g.y)};
+            return v;
+        };
+        float4 nxt = load(tid);
+        // fp32 sums run over up to 256 terms per lane (as in the brute-force kernel's tiles) before they are flushed into
+        // the fp64 accumulators: with P lanes per target that is several tiles -- a flush per 64-body tile was 6
+        // conversions and 6 fp64 additions against as little as 8 trips of pair arithmetic
+        f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
+        unsigned pending = 0;                                  // terms in the fp32 sums since the last flush
+        for (uint32_t pos0 = 0; pos0 < total; pos0 += (uint32_t)BLOCK) {
+            const uint32_t cur = (total - pos0 < (uint32_t)BLOCK) ? total - pos0 : (uint32_t)BLOCK;
+            __syncthreads();                                   // previous tile fully consumed
+            tf[wr] = nxt.x; tf[wr + 2] = nxt.y; tf[wr + 4] = nxt.z; tf[wr + 6] = nxt.w;
+            __syncthreads();
+            if (pos0 + (uint32_t)BLOCK < total) nxt = load(pos0 + (uint32_t)BLOCK + tid);   // in flight while this tile is consumed
+            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
+            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
+            // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
+            // the tile up to a multiple of P past the last real one is real or pad, never stale
+            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) / P;
+            const float4* src = tile + 2u * g;
+            // one source pair {A, B} against this lane's target: d, r^2, then the weights (plain form, or the guarded one
+            // when the wave's vote says some lane is below the law's threshold) and the accumulation
+            struct Pair { f2 dx, dy, dz, r2, sm; };
+            auto geometry = [&](const float4 A, const float4 B) -> Pair {
+                Pair q;
+                q.sm = f2{B.z, B.w};
+                q.dx = f2{A.x, A.y} - ix2;
+                q.dy = f2{A.z, A.w} - iy2;
+                q.dz = (D == 3) ? f2{B.x, B.y} - iz2 : f2{0.f, 0.f};
+                q.r2 = q.dx * q.dx;
+                q.r2 = __builtin_elementwise_fma(q.dy, q.dy, q.r2);
+                if (D == 3) q.r2 = __builtin_elementwise_fma(q.dz, q.dz, q.r2);
+                return q;
+            };
+            auto special = [&](const Pair& q) -> unsigned long long {
+                return __builtin_amdgcn_ballot_w64(q.r2.x < law_special_below<LAW>()) | __builtin_amdgcn_ballot_w64(q.r2.y < law_special_below<LAW>());
+            };
+            auto guarded = [&](const Pair& q) -> f2 {
+                float ra = q.r2.x, rb = q.r2.y;
+                asm volatile("" : "+v"(ra), "+v"(rb));   // keeps the guarded form's compares in this (rare) branch: hipcc hoists them otherwise
+                return f2{leaf_weight<D, LAW>(ra, q.sm.x, q.dx.x, q.dy.x, q.dz.x), leaf_weight<D, LAW>(rb, q.sm.y, q.dx.y, q.dy.y, q.dz.y)};
+            };
+            auto plain = [&](const Pair& q) -> f2 {
+                f2 w = {__builtin_amdgcn_rcpf(q.r2.x), __builtin_amdgcn_rcpf(q.r2.y)};
                 w = w * w;
-                w = w * f2{s.w, s.w};
+                return w * q.sm;
+            };
+            auto add = [&](const Pair& q, const f2 w) {
+                ax = __builtin_elementwise_fma(w, q.dx, ax);
+                ay = __builtin_elementwise_fma(w, q.dy, ay);
+                if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
+            };
+            unsigned it = 0;
+            for (; it + 1u < trips; it += 2u, src += 4u * P) {   // two source pairs per trip: one vote, independent chains
+                const Pair q0 = geometry(src[0], src[1]), q1 = geometry(src[2u * P], src[2u * P + 1u]);
+                f2 w0, w1;
+                if (__builtin_expect((special(q0) | special(q1)) != 0ull, 0)) { w0 = guarded(q0); w1 = guarded(q1); }     // wave-uniform, rare
+                else { w0 = plain(q0); w1 = plain(q1); }
+                add(q0, w0);
+                add(q1, w1);
             }
-            ax[q] = __builtin_elementwise_fma(w, dx, ax[q]);
-            ay[q] = __builtin_elementwise_fma(w, dy, ay[q]);
-            if (D == 3) az[q] = __builtin_elementwise_fma(w, dz, az[q]);
-        }
-    };
-
-    // ---- the source list, leaf by leaf ----
-    const uint32_t e_begin = a.list_offsets[tb.leaf], e_end = a.list_offsets[tb.leaf + 1];
-    uint32_t e_base = 0;                                       // first list entry of the chunk held in the lanes
-    unsigned n_ent = 0, e_next = 0;                            // entries in the chunk, next one to issue
-    uint32_t v_first = 0, v_len = 0, v_src = 0, off_next = 0;  // lane e: entry e_base + e
-    auto load_chunk = [&]() {
-        n_ent = (e_end - e_base < (uint32_t)kWave) ? (unsigned)(e_end - e_base) : (unsigned)kWave;
-        v_first = v_len = 0; v_src = 0xffffffffu;
-        if (lane < n_ent) {
-            v_src = a.list_sources[e_base + lane];
-            v_first = a.leaf_offsets[v_src];
-            v_len = a.leaf_offsets[v_src + 1] - v_first;
-        }
-        e_next = 0; off_next = 0;
-    };
-    // a piece = up to T bodies of one source leaf: (v, n, own) = this lane's body, the piece's size, "it is the target's leaf".
-    // Lanes past the piece's end load its last body again (an address inside the leaf, no branch) and do not write it.
-    auto issue = [&](float4& v, unsigned& n, bool& own) {      // wave-uniform control; the load stays in flight
-        n = 0u; own = false;
-        for (;;) {
-            if (e_next == n_ent) {
-                e_base += n_ent;
-                n_ent = e_next = 0;
-                if (e_base >= e_end) return;                   // the list is exhausted: an empty piece, again and again
-                load_chunk();
-                continue;
+            if (it < trips) {
+                const Pair q0 = geometry(src[0], src[1]);
+                const f2 w0 = __builtin_expect(special(q0) != 0ull, 0) ? guarded(q0) : plain(q0);
+                add(q0, w0);
             }
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)v_len, (int)e_next);
-            if (off_next >= len) { ++e_next; off_next = 0; continue; }   // empty leaves are stepped over here as well
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v_first, (int)e_next);
-            const uint32_t src_leaf = (uint32_t)__builtin_amdgcn_readlane((int)v_src, (int)e_next);
-            n = (len - off_next < T) ? (unsigned)(len - off_next) : T;
-            own = src_leaf == tb.leaf;
-            const float4* __restrict__ base = a.xm + (first + off_next);   // uniform: scalar base + per-lane 32-bit offset
-            v = base[lane < n ? lane : n - 1u];
-            off_next += n;
-            return;
-        }
-    };
-    bool guard_all = false;
-    for (int pass = 0; pass < 2; ++pass) {                     // pass 1 only after a sub-threshold pair outside the own leaf
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 12; ++k) mine[k * kWave] = 0.0;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
-        pending = 0;
-        rmin = __builtin_inff();
-        e_base = e_begin; n_ent = e_next = 0; off_next = 0;
-        int cur = 0;
-        unsigned fill = 0;                                     // bodies staged in tile[cur], the overflow in tile[cur ^ 1]
-        bool own_cur = false, own_nxt = false;                 // the tile holds bodies of the target's own leaf
-        auto consume = [&](const int buf, const unsigned trips, const bool guard) {   // trips of NS * G bodies each
-            wave_lds_sync();                                   // the tile's writes have landed
-            if (pending + trips * (unsigned)NS > 256u) flush();
-            const float4* __restrict__ src = &tile[buf][g];
-            if (guard) {
-#pragma unroll 1
-                for (unsigned k = 0; k < trips * (unsigned)NS; ++k) guarded1(src[k * (unsigned)G]);
-            } else {
-#pragma unroll 1
-                for (unsigned k = 0; k < trips; ++k) fast(src + k * (unsigned)(NS * G));   // one loop form for full and partial tiles
-            }
-            pending += trips * (unsigned)NS;
-            wave_lds_sync();                                   // the tile is free again
-        };
-        auto stage = [&](const float4 pv, const unsigned pn, const bool pown) {
-            const unsigned q = fill + lane;
-            if (lane < pn) {
-                if (q < T) tile[cur][q] = pv;
-                else tile[cur ^ 1][q - T] = pv;
-            }
-            if (pown) { own_cur = own_cur || fill < T; own_nxt = own_nxt || fill + pn > T; }
-            fill += pn;
-            if (fill >= T) {
-                consume(cur, T / (unsigned)(NS * G), guard_all || own_cur);
-                cur ^= 1; fill -= T;
-                own_cur = own_nxt; own_nxt = false;
-            }
-        };
-        float4 v0, v1;
-        unsigned n0, n1;
-        bool own0, own1;
-        issue(v0, n0, own0);
-        issue(v1, n1, own1);
-        while (n0) {                                           // two pieces per trip: their loads are issued two pieces ahead
-            stage(v0, n0, own0);
-            issue(v0, n0, own0);
-            if (!n1) break;
-            stage(v1, n1, own1);
-            issue(v1, n1, own1);
-        }
-        if (fill) {                                            // the stream's end: padded to whole trips with massless bodies far away
-            const unsigned trips = (fill + (unsigned)(NS * G) - 1u) / (unsigned)(NS * G);
-            if (lane < trips * (unsigned)(NS * G) - fill) tile[cur][fill + lane] = pad;
-            consume(cur, trips, guard_all || own_cur);
-        }
-        flush();
-        if (guard_all || __builtin_amdgcn_ballot_w64(!(rmin >= law_special_below<LAW>())) == 0ull) break;   // a NaN r^2 also redoes
-        guard_all = true;
-    }
-
-    // ---- the lane groups' sums meet, group order; every output written once ----
-    wave_lds_sync();
-    if (g_raw == 0u) {
-        double o[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) o[k] = mine[k * kWave];
-#pragma unroll 1
-        for (unsigned q = 1; q < (unsigned)G; ++q) {       // (unrolled, the 12 x (G - 1) loads cost 170 registers)
-            const double* const theirs = &red[0][q * L + p];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) o[k] += theirs[k * kWave];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned tt = p + (unsigned)t * L;
-            if (tt < c) {
-                const uint32_t s0 = tb.first + tt;
-                a.acc[s0] = o[t];
-                a.acc[(size_t)a.slots + s0] = o[4 + t];
-                if (D == 3) a.acc[2 * (size_t)a.slots + s0] = o[8 + t];
+            pending += 2u * trips;
+            if (pending + (unsigned)BLOCK > 256u || pos0 + (uint32_t)BLOCK >= total) {   // workgroup-uniform
+                ox += (double)ax.x + (double)ax.y;
+                oy += (double)ay.x + (double)ay.y;
+                oz += (double)az.x + (double)az.y;
+                ax = ay = az = f2{0.f, 0.f};
+                pending = 0;
             }
         }
     }
-}
-
-// Waves per SIMD the register allocation is held to: left alone (one wave64 per workgroup) the allocator spends 300+ VGPRs on
-// hoisted loads; at 5 waves (96 VGPRs) it spills inside the pair loop, at 4 waves (120 used) it does not.
-#ifndef NBX_LEAF_WAVES
-#define NBX_LEAF_WAVES 4
-#endif
-template <int D, int LAW>
-__global__ __launch_bounds__(kWave * kWavesPerGroup, NBX_LEAF_WAVES) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tiles[kWavesPerGroup][2][kLeafTile];
-    __shared__ double reds[kWavesPerGroup][12][kWave];
-    const unsigned wave = threadIdx.x / (unsigned)kWave;
-    const unsigned block = blockIdx.x * (unsigned)kWavesPerGroup + wave;   // wave-uniform
-    if (block >= a.n_blocks) return;
-    float4 (&tile)[2][kLeafTile] = tiles[wave];
-    double (&red)[12][kWave] = reds[wave];
-    const TargetBlock tb = a.blocks[__builtin_amdgcn_readfirstlane((int)block)];
-    switch (tb.G) {   // wave-uniform; the lane-group count is a compile-time constant of the loop it selects
-        case 1: leaf_block<D, LAW, 1>(a, tb, tile, red); break;
-        case 2: leaf_block<D, LAW, 2>(a, tb, tile, red); break;
-        case 3: leaf_block<D, LAW, 3>(a, tb, tile, red); break;
-        case 4: leaf_block<D, LAW, 4>(a, tb, tile, red); break;
-        case 5: leaf_block<D, LAW, 5>(a, tb, tile, red); break;
-        case 6: leaf_block<D, LAW, 6>(a, tb, tile, red); break;
-        case 7: leaf_block<D, LAW, 7>(a, tb, tile, red); break;
-        case 8: leaf_block<D, LAW, 8>(a, tb, tile, red); break;
-        case 9: leaf_block<D, LAW, 9>(a, tb, tile, red); break;
-        case 10: leaf_block<D, LAW, 10>(a, tb, tile, red); break;
-        case 12: leaf_block<D, LAW, 12>(a, tb, tile, red); break;
-        default: leaf_block<D, LAW, 16>(a, tb, tile, red); break;
+    if (P > 1u) {                                              // block-uniform
+        __syncthreads();
+        red[0][tid] = ox; red[1][tid] = oy; red[2][tid] = oz;
+        __syncthreads();
+        if (g == 0u)
+            for (unsigned q = 1; q < P; ++q) { ox += red[0][q * W + t]; oy += red[1][q * W + t]; oz += red[2][q * W + t]; }
+    }
+    if (valid && g == 0u) {
+        a.acc[slot] = ox;
+        a.acc[(size_t)a.slots + slot] = oy;
+        if (D == 3) a.acc[2 * (size_t)a.slots + slot] = oz;
     }
 }
 
@@ -424,10 +279,11 @@ __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restr
 }
 
 typedef void (*LeafKernel)(LeafArgs);
+template <int BLOCK>
 LeafKernel pick(int dim, int law) {
     static const LeafKernel table[2][3] = {
-        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
-        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
+        {leaf_pair_kernel<2, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, BLOCK>},
+        {leaf_pair_kernel<3, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, BLOCK>}};
     return table[dim - 2][law];
 }
 
@@ -488,45 +344,30 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
-    // Target blocks: a leaf of c targets is cut into k pieces of ceil(c / k), four targets per lane.  A piece of t targets runs
-    // G lane groups (the largest of {1..10, 12, 16} within 64 / ceil(t / 4)), every lane making (sources / G) trips of 28 VALU,
-    // and stages the leaf's source list once (about half an instruction per body, plus the block's fixed part): k minimises
-    // k x (sources x (28 / G + 0.5) + 300).  32 targets: one block at 8 groups; 34: one block at 7.
-    auto groups_of = [&](uint32_t piece) -> uint32_t {
-        const uint32_t lanes = (piece + 3) / 4;
-        if (lanes > (uint32_t)kWave) return 0;
-        uint32_t g = (uint32_t)kWave / lanes;
-        if (g > (uint32_t)kMaxGroups) g = (uint32_t)kMaxGroups;
-        if (g == 11) g = 10;
-        if (g > 12 && g < 16) g = 12;
-        return g;
+    size_t nonempty = 0;
+    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
+    // block size by the mean leaf: up to 80 bodies per leaf one wave64 per block wastes fewer lanes than two
+    const uint32_t block = (nonempty && slots / nonempty <= 80) ? (uint32_t)kLeafBlockSmall : (uint32_t)kLeafBlock;
+    // Target blocks.  A block of c targets runs floor(block / c) lanes per target (kernel), so c just above block / 2 wastes
+    // almost half the lanes: such a piece is cut in two when that fills the lanes better by more than the cost of staging
+    // the source stream a second time (~15 %): 33..42 targets in a wave64 become two blocks at 3 lanes per target.
+    auto lane_use = [&](uint32_t c) -> double {
+        uint32_t lanes = block / c;
+        if (lanes > (uint32_t)kMaxLanesPerTarget) lanes = (uint32_t)kMaxLanesPerTarget;
+        return (double)(c * lanes) / (double)block;
     };
     std::vector<TargetBlock> blocks;
-    for (size_t l = 0; l < n_leaves; ++l) {
-        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
-        if (!c) continue;
-        double sources = 0.0;
-        for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e)
-            sources += (double)(leaf_offsets[list_sources[e] + 1] - leaf_offsets[list_sources[e]]);
-        const uint32_t k_min = (c + (uint32_t)(kWave * kMaxTargetsPerLane) - 1) / (uint32_t)(kWave * kMaxTargetsPerLane);
-        uint32_t best_k = k_min;
-        double best = 1e300;
-        for (uint32_t k = k_min; k <= k_min + 3 && k <= c; ++k) {
-            const uint32_t g = groups_of((c + k - 1) / k);
-            if (!g) continue;
-            const double v = (double)k * (sources * (28.0 / g + 0.5) + 300.0);
-            if (v < best * (1.0 - 1e-9)) { best = v; best_k = k; }
+    for (size_t l = 0; l < n_leaves; ++l)
+        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block) {
+            const uint32_t c = (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block;
+            const uint32_t half = (c + 1) / 2;
+            if (c >= 2 && lane_use(half) > 1.15 * lane_use(c)) {
+                blocks.push_back(TargetBlock{(uint32_t)l, f, half});
+                blocks.push_back(TargetBlock{(uint32_t)l, f + half, c - half});
+            } else {
+                blocks.push_back(TargetBlock{(uint32_t)l, f, c});
+            }
         }
-        const uint32_t piece = (c + best_k - 1) / best_k;
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += piece) {
-            TargetBlock tb = {};
-            tb.leaf = (uint32_t)l; tb.first = f; tb.count = (leaf_offsets[l + 1] - f < piece) ? leaf_offsets[l + 1] - f : piece;
-            tb.L = (tb.count + 3) / 4;
-            tb.G = groups_of(tb.count);
-            tb.inv_L = 65536u / tb.L + 1u;
-            blocks.push_back(tb);
-        }
-    }
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
@@ -565,9 +406,10 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipGetLastError());
     LeafArgs a;
     a.xm = xm; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
-    a.blocks = d_blocks; a.n_blocks = (uint32_t)blocks.size(); a.acc = acc;
+    a.blocks = d_blocks; a.acc = acc;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)((blocks.size() + kWavesPerGroup - 1) / kWavesPerGroup)), dim3(kWave * kWavesPerGroup), 0, d.stream, a);
+    hipLaunchKernelGGL(block == (uint32_t)kLeafBlockSmall ? pick<kLeafBlockSmall>(dim, law) : pick<kLeafBlock>(dim, law),
+                       dim3((unsigned)blocks.size()), dim3(block), 0, d.stream, a);
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
