@@ -241,7 +241,7 @@ int nbx_ctx_set_law(nbx_ctx* ctx, int law);
  *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
  *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
  *    calibrated default.  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
- *    Newtonian law, or a non-fast variant.  At most 1/64 of a shard's targets (at least 16,384) are re-evaluated per force
+ *    Newtonian law, or a non-fast variant.  At most 1/16 of a shard's targets (at least 16,384) are re-evaluated per force
  *    evaluation; nbx_ctx_refine_stats reports how many the rule selected and how many were re-evaluated. */
 int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);
 /* After a mixed-mode force evaluation: selected = targets the rule listed, refined = those re-evaluated in fp64

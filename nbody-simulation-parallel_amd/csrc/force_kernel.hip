@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, WAVES) void accel_lds_kernel(KArgs a) {
 // LIST = 0: every target of the chunk; the slice's fp64 sum v leaves as TWO fp32 planes of acc, hi = (float)v and
 //           lo = (float)(v - hi) (planes 2*slice and 2*slice+1): the consumers already add the planes in fp64 in plane
 //           order (state_kernels.hip sum_partials), which puts v back together to 2^-48 -- no consumer knows about this kernel.
-// LIST = 1: the targets listed in strict_list[0 .. counters[3]) (the mixed mode's suspects, refine_select_kernel); one
-//           target per lane, workgroup (x, y) takes list blocks x, x + gridDim.x, ... against source slice y and writes
+// LIST = 1: the targets listed in strict_list[0 .. counters[3]) (the mixed mode's suspects, refine_select_kernel); TPL
+//           targets per lane, workgroup (x, y) takes list blocks x, x + gridDim.x, ... against source slice y and writes
 //           strict_acc[y][k][slot] in fp64; refine_fold_kernel adds the slices and rewrites the targets' planes.
 // -------------------------------------------------------------------------------------------------
 template <int D, int NR, int MAG>
@@ -323,7 +323,6 @@ __device__ __forceinline__ void store_hi_lo(const KArgs& a, float* __restrict__ 
 // relative error of a cancelling sum is measured against (tests: backward error of the fp32 path for EVERY body).
 template <int D, int TPL, int WAVES, int UNROLL, int NR, int LIST, int MAG = 0>
 __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
-    static_assert(!LIST || TPL == 1, "listed targets: one per lane");
     static_assert(!(LIST && MAG), "magnitude sums: whole-chunk launches only");
     __shared__ Tile64 tile[2][kTile];
     const unsigned tid = threadIdx.x;
@@ -332,16 +331,16 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
     const unsigned n_list = LIST ? a.counters[3] : 0u;
     const unsigned n_listed = n_list < a.strict_cap ? n_list : a.strict_cap;
-    const unsigned nblk = LIST ? (n_listed + 255u) / 256u : bx + 1u;
+    const unsigned nblk = LIST ? (n_listed + 256u * TPL - 1u) / (256u * TPL) : bx + 1u;
 
     for (unsigned tb = bx; tb < nblk; tb += LIST ? gridDim.x : nblk) {
         unsigned idx[TPL];
         double ix[TPL], iy[TPL], iz[TPL], ox[TPL], oy[TPL], oz[TPL], om[MAG ? TPL : 1];
-        const unsigned slot = tb * 256u + tid;
-        const bool valid = !LIST || slot < n_listed;
+        const unsigned slot0 = tb * (256u * TPL) + tid;   // list slot (LIST) or target index of this lane's q-th target: slot0 + 256 q
 #pragma unroll
         for (int q = 0; q < TPL; ++q) {
-            idx[q] = LIST ? a.strict_list[valid ? slot : 0] : tb * (256u * TPL) + q * 256u + tid;
+            const unsigned slot = slot0 + q * 256u;
+            idx[q] = LIST ? a.strict_list[slot < n_listed ? slot : 0] : slot;
             ix[q] = (double)tp[idx[q]];
             iy[q] = (double)tp[(size_t)a.pad + idx[q]];
             iz[q] = (D == 3) ? (double)tp[2 * (size_t)a.pad + idx[q]] : 0.0;
@@ -374,11 +373,15 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
             buf ^= 1;
         }
         if (LIST) {
-            if (valid) {
-                double* __restrict__ o = a.strict_acc + (size_t)by * D * a.strict_cap;
-                o[slot] = ox[0];
-                o[(size_t)a.strict_cap + slot] = oy[0];
-                if (D == 3) o[2 * (size_t)a.strict_cap + slot] = oz[0];
+            double* __restrict__ o = a.strict_acc + (size_t)by * D * a.strict_cap;
+#pragma unroll
+            for (int q = 0; q < TPL; ++q) {
+                const unsigned slot = slot0 + q * 256u;
+                if (slot < n_listed) {
+                    o[slot] = ox[q];
+                    o[(size_t)a.strict_cap + slot] = oy[q];
+                    if (D == 3) o[2 * (size_t)a.strict_cap + slot] = oz[q];
+                }
             }
             __syncthreads();   // the next list block reuses the tile buffers
         } else {
@@ -844,7 +847,10 @@ CloseKernels close_kernels() {
     k.potential_soft[0] = potential_kernel<2, 1>; k.potential_soft[1] = potential_kernel<3, 1>;
     k.potential_newton[0] = potential_kernel<2, 2>; k.potential_newton[1] = potential_kernel<3, 2>;
     k.refine_select[0] = refine_select_kernel<2>; k.refine_select[1] = refine_select_kernel<3>;
-    k.strict_list[0] = accel_f64_kernel<2, 1, 4, 4, 2, 1>; k.strict_list[1] = accel_f64_kernel<3, 1, 4, 4, 2, 1>;
+    // the mixed mode's re-evaluation: one listed target per lane, ONE Newton step (1/r^2 good to 2.2e-15 where the goal is 1e-5),
+    // unroll 8.  Measured at N = 2^20, 7,703 targets (profiles/r3/mixed_mode_list_kernel_ab.txt): two Newton steps 5.66 ms, one
+    // 5.23, one + unroll 8: 5.12; two targets per lane 9.26 (126 VGPRs, half as many workgroups of twice the length).
+    k.strict_list[0] = accel_f64_kernel<2, 1, 4, 8, 1, 1>; k.strict_list[1] = accel_f64_kernel<3, 1, 4, 8, 1, 1>;
     k.refine_fold[0] = refine_fold_kernel<2>; k.refine_fold[1] = refine_fold_kernel<3>;
     return k;
 }

@@ -263,10 +263,10 @@ int ensure_acc(nbx_ctx* c) {
             c->qsum_slices_alloc = c->splits;
         }
         if (refine_active(c, c->variant) && !c->strict_list) {
-            // room for 1/64 of the shard (at least 16,384 targets): the default rule lists 0.2-0.8 % of uniform or Plummer
-            // bodies.  As many strict slices (<= 256) as keep their fp64 partial sums within 256 MiB: a short list still
-            // spreads over the chip (one list block x 256 slices = 256 workgroups), a long one has the blocks for it.
-            c->strict_cap = c->pad / 64 > 16384u ? c->pad / 64 : 16384u;
+            // room for 1/16 of the shard (at least 16,384 targets): the default rule lists 0.3-0.8 % of uniform or Plummer 3D
+            // bodies and ~3 % of uniform 2D bodies.  As many strict slices (<= 256) as keep their fp64 partial sums within
+            // 256 MiB: a short list still spreads over the chip (one list block x 170-256 slices), a long one has the blocks.
+            c->strict_cap = c->pad / 16 > 16384u ? c->pad / 16 : 16384u;
             if (c->strict_cap > c->pad) c->strict_cap = c->pad;
             const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
             size_t sl = kStrictAccBytesMax / ((size_t)c->dim * c->strict_cap * sizeof(double));
