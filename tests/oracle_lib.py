@@ -255,10 +255,14 @@ def have_reference() -> bool:
 # Evidence (round 3, every body against the strict fp64 kernel on the device, itself within 3e-13 of the oracle on >= 1,024
 # sampled rows; profiles/r3/accuracy_all_bodies.jsonl):
 #                                   bodies     max backward   max rel, kappa<=4   over 1e-5 (default)   over 1e-5 (mixed)
+#   uniform 3D N=65,536, seed 2       65,536     2.06e-6          2.16e-6               0 (max 6.5e-6)          0
 #   uniform 3D N=2^20, seed 3      1,048,576     2.71e-6          4.18e-6              39 (max 2.6e-5)          0
 #   uniform 3D N=2^20, seed 1      1,048,576     3.12e-6            --                 44 (max 3.5e-5)          0
+#   uniform 3D N=2^20, seed 4      1,048,576     4.55e-6          6.13e-6              41 (max 2.7e-5)          0
+#   uniform 3D N=2^22, seed 6      4,194,304     4.13e-6          4.36e-6             550 (max 7.2e-5)          0 (max 9.8e-6)
 #   Plummer N=2^22 (config 5)      4,194,304     6.70e-6          6.71e-6              56 (max 3.5e-5)          0
-# TOL_BACKWARD = 1e-5 = 1.5 x the largest backward error among those 6.3 million bodies.  Where it comes from: with unit
+#   uniform 2D N=2^20, seed 3      1,048,576     2.99e-6          4.82e-6           3,006 (max 3.0e-4)          8 (max 1.16e-5)
+# TOL_BACKWARD = 1e-5 = 1.5 x the largest backward error among those 12.6 million bodies.  Where it comes from: with unit
 # roundoff u = 2^-24 = 6e-8, one fp32 pair term m*d/(r^2)^2 carries at most 18u, and a term that dominates its sum then rides
 # through up to 511 fp32 additions (the rest of its 256-source tile, then up to 256 tile flushes of its slice): 13u rms; the
 # largest of millions of such sums sits near 6 sigma: 18u + 6.5 * 13u = 102u = 6.1e-6 (observed 112u on a body of the Plummer
