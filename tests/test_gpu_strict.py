@@ -209,3 +209,36 @@ def test_every_body_of_config5_n4194304(nbx, oracle):
     assert rec["default"]["max_rel_kappa_le_4"] <= TOL_REL, rec["default"]
     assert rec["mixed"]["max_rel"] <= TOL_REL and rec["mixed"]["n_over_tol"] == 0, rec["mixed"]
     assert rec["mixed"]["refined"] == rec["mixed"]["selected"] <= n // 50, rec["mixed"]
+
+
+def test_mixed_mode_capacity_overflow_and_node_layer(nbx, oracle):
+    """More suspects than the re-evaluation holds (capacity = max(16,384, 1/16 of the shard)): the first `capacity` listed
+    targets come back in fp64, the others keep their fp32 result, the counts say so, nothing is lost or written twice.  And the
+    single-process node layer (nbx_node_set_refine: every rank refines its own shard after its REMOTE pass)."""
+    n, dim = 40000, 3
+    b = _inputs(oracle, 55, n, dim)
+    rows = np.arange(0, n, 13)
+    ref = oracle.force_rows_omp_2(b, rows)
+    S = oracle.force_magnitude_sums(b, rows)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.compute_accel()
+        plain = c.forces(oracle.G)
+        c.set_refine(1e-7, 1e6)                     # every target is a suspect
+        c.compute_accel()
+        sel, done = c.refine_stats()
+        mixed = c.forces(oracle.G)
+    assert sel == n and done == 16384, (sel, done)
+    changed = (mixed != plain).any(axis=1)
+    assert 16000 <= changed.sum() <= 16384          # (a re-evaluated target may happen to round to the same fp32-plane pair)
+    e = np.sqrt(((mixed[rows] - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
+    assert (e[changed[rows]] <= 1e-7).all() and (e <= 1e-5).all()
+    from oracle_lib import assert_force_parity
+    assert_force_parity(mixed[rows], ref, S, "capacity overflow")
+    m = 6000
+    bb = _inputs(oracle, 56, m, dim)
+    with nbx.Node(m, dim, [0, 0, 0]) as node:
+        node.upload(bb)
+        node.set_refine(1e-7, 1e6)
+        f = node.forces(oracle.G)
+    _assert_strict(f, oracle.brute_force_seq(bb), oracle.force_magnitude_sums(bb), "node layer, all targets refined")
