@@ -53,6 +53,7 @@ def test_strerror_and_variants(nbx):
     assert b"no CPU fallback" in lib.nbx_strerror(2)
     names = nbx.variants()
     assert len(names) == len(set(names)) and 0 <= lib.nbx_default_variant() < len(names)
+    assert "strict_f64_t4" in names and "strict_f64_t4_mag" in names and names[lib.nbx_default_variant()].startswith("fastpk")
     assert lib.nbx_variant_name(len(names)) == b"?"
 
 
@@ -86,7 +87,9 @@ def test_argument_validation(nbx):
     assert lib.nbx_device_count(None) == 1
     for fn, args in ((lib.nbx_ctx_compute_accel, (None, 0)), (lib.nbx_ctx_kick_drift, (None, 1.0, 1.0)),
                      (lib.nbx_ctx_step, (None, 1.0, 1.0, 1)), (lib.nbx_ctx_synchronize, (None,)),
-                     (lib.nbx_ctx_set_tuning, (None, 0, 0))):
+                     (lib.nbx_ctx_set_tuning, (None, 0, 0)), (lib.nbx_ctx_set_refine, (None, 1e-5, 0.0)),
+                     (lib.nbx_ctx_refine_stats, (None, None, None)), (lib.nbx_ctx_get_aux, (None, None)),
+                     (lib.nbx_node_set_refine, (None, 1e-5, 0.0))):
         assert fn(*args) == 1
     assert lib.nbx_ctx_destroy(None) == 0
     assert lib.nbx_brute_force_forces(None, 4, 3, 56, 1.0, 0, None, None) == 1
