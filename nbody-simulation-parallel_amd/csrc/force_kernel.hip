@@ -489,6 +489,8 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
             if (SOFT || !a.bad_flag[i]) {  // flagged targets belong to close_set_path + scatter_close_kernel
                 store_result<D>(a, out, i, h ? ox[q].y : ox[q].x, h ? oy[q].y : oy[q].x, h ? oz[q].y : oz[q].x);
                 if (QS) { const float v = h ? qq[q].y : qq[q].x; qout[i] = a.accumulate ? qout[i] + v : v; }
+            } else if (QS) {
+                qout[i] = __builtin_inff();   // a close-set target of this pass keeps no spread sum: it is always a suspect
             }
         }
     }
