@@ -7,31 +7,46 @@
 // All three are m_j d / r^4 sums; they differ in sign and in what happens below ~1e-5 separation.
 //
 // Mapping to CDNA4.  The reference walks pointer lists per (body, neighbour leaf) work item and adds into
-// forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the bodies are gathered once into
-// leaf order as fp32 {x,y,z,m} (one 16-byte load per body), and the work is target-leaf-major: one workgroup (one wave64 when the mean
-// leaf holds <= 80 bodies, else two) owns up to 64 (128) targets of ONE leaf and walks that leaf's source-leaf list as one
-// stream of bodies staged through LDS in tiles of one body per lane {x,y,z,m}; fp32 sums per tile, flushed into fp64
-// second-level accumulators.  No atomics, a fixed summation order (list order, then leaf order), every output written
-// once.  The comment at the kernel says how the lanes share the work.  Leaves are small (the reference caps them at 100
-// bodies, methods.h:26), so the launch is tens of thousands of short workgroups; HBM traffic is 16 B per (target block,
-// source body) served mostly from L2.  VALU-issue-bound (counters: profiles/r2/pmc_leaf_pair_kernel.txt): 76 % of the
-// instructions are the pair loop, the rest stages tiles and flushes sums; tiles of 256 bodies instead of 64, or half the
-// LDS reads, changed nothing measurable.
+// forces[body] from several work items at once (fmm_parlay.cpp:986-1020).  Here the work is target-leaf-major and
+// everything the kernel follows is laid out for it once per call:
+//  * bodies are gathered into leaf order as fp32 SOURCE PAIRS {xa,xb,ya,yb},{za,zb,ma,mb} (32 B; a leaf of odd size
+//    ends in a massless body far away), so a source leaf is a run of whole pairs that is copied into LDS as it lies
+//    and read back with ds_read_b128 straight into the aligned register pairs of v_pk_*_f32;
+//  * a leaf's source list becomes a few COPY OPS on the host: consecutive list entries whose leaves are neighbours
+//    in leaf order are merged (the 27 cells of a grid neighbourhood are 9 runs), with the running length of the
+//    stream they form -- no list walk, no leaf-offset lookup and no prefix sum on the device;
+//  * one workgroup = two wave64 = ONE leaf: the waves share the staged tiles (512 bodies) and each owns one PIECE of
+//    the leaf's targets.  A piece of c targets runs floor(64 / c) lanes per target (at most 8), which split the
+//    tile's pairs between them; the host cuts the leaf where the two pieces together waste the fewest lanes
+//    (43 targets: 11 x 5 lanes + 32 x 2 lanes = 96 % of the lanes busy; one wave64 with one lane each: 67 %);
+//  * the law's special cases sit below r^2 = 1e-9.  A target whose fp32 coordinates are all >= 2^14 in magnitude
+//    cannot own such a pair other than with an identical position (the brute-force kernel's argument,
+//    nbx_internal.h: distinct fp32 numbers that large differ by >= 2^-10), so a block of such targets runs the pair
+//    loop with no compare at all: r^2 biased by 2^-47, an identical position contributes m 2^94 x 0 = 0 as every law
+//    asks.  The host decides per block; the other blocks take the guarded loop (one v_cmp per pair, a wave vote,
+//    and the law's exact weights for the wave that saw a pair below the threshold).
+// fp32 sums over at most 256 terms per lane, flushed into fp64 accumulators.  No atomics, a fixed summation order,
+// every output written once.  Leaves are small (the reference caps them at 100 bodies, methods.h:26), so the launch
+// is tens of thousands of short workgroups; HBM traffic is 16 B per (workgroup, source body), served mostly from L2.
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 using namespace nbx;
 
 namespace {
 
-// targets per workgroup = source bodies per LDS tile: 128 lanes (two wave64), or one wave64 when the leaves are small
-// (the mean leaf of the reference's trees is well under 100 bodies, methods.h:26) so that fewer lanes idle
-constexpr int kLeafBlock = 128;
-constexpr int kLeafBlockSmall = 64;
-constexpr int kMaxLanesPerTarget = 8;   // a block of few targets gives each up to this many lanes (they split the sources)
+constexpr int kWaves = 2;
+constexpr int kThreads = 64 * kWaves;          // two wave64 per workgroup
+constexpr int kUnitsPerLane = 4;               // 16-byte units (= bodies) a lane stages per tile (the kernel names that many registers)
+constexpr int kTileUnits = kThreads * kUnitsPerLane;   // 512 bodies = 256 source pairs = 8 KB of LDS
+constexpr int kPadPairs = 16;                  // massless pairs behind the tile's last one: the lane groups' last trips reach up to 2 P - 1 past it
+constexpr int kMaxOps = 64;                    // copy ops held in LDS at a time (longer lists go in chunks)
+constexpr int kMaxLanesPerTarget = 8;          // a piece of few targets gives each up to this many lanes (they split the sources)
+constexpr unsigned kFlushTerms = 248;          // fp32 terms per lane between flushes into the fp64 sums (+ 2 for a closing single pair)
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
 constexpr float kTreeSkipF = 0x1.12e0c0p-30f;   // 1.00000008e-9  (octree.cpp:119, bvh.cpp:167: dist_sq < 1e-9)
@@ -40,21 +55,31 @@ constexpr float kNormZeroF = 0x1.79ca12p-67f;   // 1.00000005e-20 (vector.h:93-9
 constexpr float kSameF = 1.0e-14f;              // largest fp32 <= 1e-14 (fmm_parlay.cpp:995-1000: |d_k| > 1e-14 -> distinct)
 static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double)kNormZeroF >= 1e-20 && (double)kSameF <= 1e-14,
               "fp32 thresholds must sit on the right side of the fp64 ones");
+constexpr float kFar = 1.0e18f;                 // pad bodies: massless, r^2 ~ 1e36 is finite in fp32 and the weight underflows to 0
+static_assert(kTreeSkipF < 9.0e-7f, "a target outside the close set (nbx_internal.h) has no non-zero r^2 below 9.5e-7: no law's special case can apply to it");
 
-struct TargetBlock {
-    uint32_t leaf;     // target leaf
-    uint32_t first;    // first target slot (leaf order)
-    uint32_t count;    // <= the launch's block size
+struct Piece {
+    uint32_t first;    // first target (padded slot)
+    uint32_t count;    // <= 64; 0: this wave only helps staging
+};
+struct LeafBlock {     // one workgroup; read with scalar loads
+    uint32_t op_lo, op_n;   // the leaf's copy ops
+    uint32_t pad_[2];
+    Piece piece[2];
+};
+static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
+struct CopyOp {
+    uint32_t end;      // length of the leaf's source stream up to and including this run, in 16-byte units
+    uint32_t base;     // unit of the run's first body minus the stream position it lands on (mod 2^32): source = base + position
 };
 
 struct LeafArgs {
-    const float4* __restrict__ xm;     // [slots] leaf-ordered {x, y, z (0 in 2D), m}: one 16-byte load stages a body
-    uint32_t slots;
-    const uint32_t* __restrict__ leaf_offsets;
-    const uint32_t* __restrict__ list_offsets;
-    const uint32_t* __restrict__ list_sources;
-    const TargetBlock* __restrict__ blocks;
-    double* __restrict__ acc;          // [dim][slots]
+    const float4* __restrict__ xp;     // [pslots] units: pair p = units 2p {xa,xb,ya,yb} and 2p+1 {za,zb,ma,mb}
+    uint32_t pslots;                   // padded slots = 2 x pairs
+    const CopyOp* __restrict__ ops;
+    const LeafBlock* __restrict__ blocks;
+    double* __restrict__ acc;          // [dim][pslots]
+    const uint32_t* __restrict__ max_mass_bits;   // bit pattern of the largest |mass| as fp32 (leaf_gather_kernel); a NaN compares above every number
 };
 
 // Weight of d = p_j - p_i in the law's sum for ONE pair, every special case included: m_j / r^4 for an ordinary pair.
@@ -90,201 +115,291 @@ __device__ __forceinline__ constexpr float law_special_below() {
     return LAW == NBX_LAW_BRUTE ? kR2SkipF : LAW == NBX_LAW_TREE_LEAF ? kTreeSkipF : kSmoothF;
 }
 
-// One workgroup = up to BLOCK targets of one leaf against that leaf's source list.
-//  * The list is read ONCE, by the lanes in parallel (lane k: list entry k -> that source leaf's slot range), and turned
-//    into one stream of source bodies by a prefix sum over the leaf sizes in LDS; tiles are then cut from the STREAM
-//    (BLOCK consecutive stream positions, whatever leaves they fall in), not from single leaves.  Walking the list leaf
-//    by leaf cost a chain of three dependent loads per ~30-body tile and left half of every tile empty.
-//  * Two SOURCES per lane and iteration, as packed fp32 pairs (v_pk_add/fma/mul_f32: 3 + 3 + 2 + 3 packed instructions and
-//    two v_rcp_f32 for two pairs, where one source at a time took 12 scalar ones and a v_rcp per pair).  The tile is
-//    staged in LDS as source PAIRS {xa,xb,ya,yb},{za,zb,ma,mb}, so each ds_read_b128 lands in aligned register pairs.
-//  * The law's special cases (skip / smoothing below ~1e-5 separation, and a body meeting itself in its own leaf) are
-//    rare: one v_cmp per pair and a wave-wide vote; only a wave in which some lane sees r^2 below the law's threshold
-//    takes the guarded scalar weights (leaf_weight) for that source pair -- which is every pair of the target's own leaf
-//    (each source there is some lane's own body) and next to nothing else.
-//  * Leaves are small (the reference caps them at 100 bodies; a uniform grid at 32 per leaf leaves half of a wave64 idle
-//    with one lane per target): a block whose targets fill at most half / a quarter of the lanes gives each target 2 / 4
-//    lanes, which split the source pairs of every tile between them; their fp64 sums meet in LDS at the end, in lane
-//    group order (deterministic).
-template <int D, int LAW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void leaf_pair_kernel(LeafArgs a) {
-    __shared__ float4 tile[BLOCK + 2 * kMaxLanesPerTarget];   // BLOCK/2 source pairs x 2 float4, + pad pairs past the end
-    __shared__ double red[3][BLOCK];
-    __shared__ uint32_t seg_end[BLOCK];     // stream position one past the last body of list entry k (inclusive prefix sum)
-    __shared__ uint32_t seg_first[BLOCK];   // slot of stream position 0 if entry k started there: slot = seg_first[k] + position
-    const unsigned tid = threadIdx.x;
-    const TargetBlock tb = a.blocks[blockIdx.x];
-    // lanes per target: as many whole groups of `count` lanes as the block holds (21 targets in a wave64: 3 lanes each)
-    const unsigned W = tb.count ? tb.count : 1u;
-    const unsigned fit = (unsigned)BLOCK / W;
+// One source pair {A, B} (two float4 of the tile) against this lane's target.
+template <int D>
+struct PairTerm {
+    f2 dx, dy, dz, r2, sm;
+    __device__ __forceinline__ PairTerm(const float4 A, const float4 B, const f2 ix2, const f2 iy2, const f2 iz2, const f2 bias) {
+        sm = f2{B.z, B.w};
+        dx = f2{A.x, A.y} - ix2;
+        dy = f2{A.z, A.w} - iy2;
+        dz = (D == 3) ? f2{B.x, B.y} - iz2 : f2{0.f, 0.f};
+        r2 = __builtin_elementwise_fma(dx, dx, bias);
+        r2 = __builtin_elementwise_fma(dy, dy, r2);
+        if (D == 3) r2 = __builtin_elementwise_fma(dz, dz, r2);
+    }
+    __device__ __forceinline__ f2 plain() const {
+        f2 w = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+        w = w * w;
+        return w * sm;
+    }
+    template <int LAW>
+    __device__ __forceinline__ unsigned long long special() const {
+        return __builtin_amdgcn_ballot_w64(r2.x < law_special_below<LAW>()) | __builtin_amdgcn_ballot_w64(r2.y < law_special_below<LAW>());
+    }
+    template <int LAW>
+    __device__ __forceinline__ f2 guarded() const {
+        float ra = r2.x, rb = r2.y;
+        asm volatile("" : "+v"(ra), "+v"(rb));   // keeps the guarded form's compares in this (rare) branch: hipcc hoists them otherwise
+        return f2{leaf_weight<D, LAW>(ra, sm.x, dx.x, dy.x, dz.x), leaf_weight<D, LAW>(rb, sm.y, dx.y, dy.y, dz.y)};
+    }
+};
+
+// The sums of one lane: fp32 per-tile level, fp64 second level.
+template <int D>
+struct Sums {
+    f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
+    double* o;              // this lane's fp64 sums, kept in LDS (they are touched once per ~250 terms; 6 VGPRs less): o[0], o[kThreads], o[2 kThreads]
+    unsigned pending = 0;   // terms in the fp32 sums since the last flush (wave-uniform)
+    __device__ __forceinline__ void add(const PairTerm<D>& q, const f2 w) {
+        ax = __builtin_elementwise_fma(w, q.dx, ax);
+        ay = __builtin_elementwise_fma(w, q.dy, ay);
+        if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
+    }
+    __device__ __forceinline__ void flush() {
+        o[0] += (double)ax.x + (double)ax.y;
+        o[kThreads] += (double)ay.x + (double)ay.y;
+        if (D == 3) o[2 * kThreads] += (double)az.x + (double)az.y;
+        ax = ay = az = f2{0.f, 0.f};
+        pending = 0;
+    }
+};
+
+// T source pairs (T odd) at s, for this lane's target: (T - 1) / 2 trips of two pairs -- two independent dependency chains --
+// and a closing single pair.  GUARD: the law's special cases are possible for this wave's targets (one wave vote per trip);
+// without it a trip is 26 VALU (6 v_pk_add, 6 + 6 v_pk_fma, 4 v_pk_mul, 4 v_rcp_f32) and half an address increment, and the
+// LDS reads of the trip after next are in flight while a trip is computed.
+template <int D, int LAW, bool GUARD>
+__device__ __forceinline__ void consume(const float4* __restrict__ s, const unsigned T, const f2 ix2, const f2 iy2, const f2 iz2, Sums<D>& S) {
+    const f2 bias = GUARD ? f2{0.f, 0.f} : f2{kTiny, kTiny};
+    const unsigned ndt = T >> 1;
+    unsigned done = 0;
+    while (done < ndt) {                                    // wave-uniform bookkeeping
+        if (S.pending + 4u > kFlushTerms) S.flush();
+        const unsigned room = (kFlushTerms - S.pending) >> 2;
+        const unsigned n = __builtin_amdgcn_readfirstlane((ndt - done < room) ? ndt - done : room);
+        if (!GUARD) {
+            // the trip after next is read while this one is computed: two register sets, taking turns (no copies)
+            auto trip = [&](const float4 A0, const float4 B0, const float4 A1, const float4 B1) {
+                const PairTerm<D> q0(A0, B0, ix2, iy2, iz2, bias), q1(A1, B1, ix2, iy2, iz2, bias);
+                const f2 w0 = q0.plain(), w1 = q1.plain();
+                S.add(q0, w0);
+                S.add(q1, w1);
+            };
+            float4 a0 = s[0], a1 = s[1], a2 = s[2], a3 = s[3];
+            unsigned i = n;
+            for (; i >= 2u; i -= 2u, s += 8) {
+                const float4 b0 = s[4], b1 = s[5], b2 = s[6], b3 = s[7];
+                __builtin_amdgcn_sched_barrier(0);
+                trip(a0, a1, a2, a3);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = s[8]; a1 = s[9]; a2 = s[10]; a3 = s[11];     // may lie past the segment: read, not used (the tile has room)
+                __builtin_amdgcn_sched_barrier(0);
+                trip(b0, b1, b2, b3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i) { trip(a0, a1, a2, a3); s += 4; }
+        } else
+        for (unsigned i = n; i != 0u; --i, s += 4) {
+            const PairTerm<D> q0(s[0], s[1], ix2, iy2, iz2, bias), q1(s[2], s[3], ix2, iy2, iz2, bias);
+            f2 w0, w1;
+            if (GUARD && __builtin_expect((q0.template special<LAW>() | q1.template special<LAW>()) != 0ull, 0)) {   // wave-uniform, rare
+                w0 = q0.template guarded<LAW>();
+                w1 = q1.template guarded<LAW>();
+            } else {
+                w0 = q0.plain();
+                w1 = q1.plain();
+            }
+            S.add(q0, w0);
+            S.add(q1, w1);
+        }
+        S.pending += 4u * n;
+        done += n;
+    }
+    const PairTerm<D> q0(s[0], s[1], ix2, iy2, iz2, bias);
+    const f2 w0 = (GUARD && __builtin_expect(q0.template special<LAW>() != 0ull, 0)) ? q0.template guarded<LAW>() : q0.plain();
+    S.add(q0, w0);
+    S.pending += 2u;
+}
+
+// One workgroup = one target leaf (or 128 targets of a larger one) against the stream of source pairs its copy ops describe.
+//  * Staging: a tile is kTileUnits consecutive stream positions; lane l copies positions l, l + 128, ... (one 16-byte
+//    load and one ds_write_b128 each, conflict-free); the run a position falls in is found by stepping a cursor through the
+//    ops' running lengths in LDS -- it only ever moves forward and a run holds ~100 bodies.  The next tile's loads
+//    are issued before the current tile is consumed.
+//  * The pair loop: lane group g of a piece takes the T consecutive pairs from g T on, T = ceil(pairs / P) made odd:
+//    consecutive pairs sit at immediate offsets of one address register, and the groups' addresses differ by odd
+//    multiples of 32 B, which no two of <= 8 groups share a bank on.  Pairs past the tile's end are the pad pairs.
+//  * A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips i == j by
+//    index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
+template <int D, int LAW>
+__global__ __launch_bounds__(kThreads) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ float4 tile[kTileUnits + 2 * kPadPairs + 16];   // + what the pipelined pair loop reads ahead of its last trip
+    __shared__ uint32_t op_end[kMaxOps], op_base[kMaxOps];
+    static_assert(kUnitsPerLane == 2 || kUnitsPerLane == 4, "the kernel names two or four staging registers");
+        const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LeafBlock* __restrict__ bp = a.blocks + blockIdx.x;
+    const uint32_t op_lo = bp->op_lo, op_n = bp->op_n;
+    const uint32_t max_mass_bits = *a.max_mass_bits;
+    const uint32_t p_first = bp->piece[wave].first, p_count = bp->piece[wave].count;
+    // lanes per target: as many whole groups of `count` lanes as the wave holds (21 targets: 3 lanes each)
+    const unsigned W = p_count ? p_count : 1u;
+    const unsigned fit = 64u / W;
     const unsigned P = fit < (unsigned)kMaxLanesPerTarget ? fit : (unsigned)kMaxLanesPerTarget;
-    const unsigned t = tid % W, g_raw = tid / W;
-    const bool valid = g_raw < P;                              // lanes left over compute along with group 0, unused
+    const unsigned inv_P = (65536u + P - 1u) / P;                 // q / P = (q * inv_P) >> 16 for q < 2^13
+    // lane / W through fp32: (lane + 0.5) / W is at least 1/128 away from an integer, the arithmetic is good to 2e-5
+    const unsigned g_raw = (unsigned)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)W));
+    const unsigned t = lane - g_raw * W;
+    const bool valid = p_count != 0u && g_raw < P;             // lanes left over compute along with group 0, unused
     const unsigned g = valid ? g_raw : 0u;
-    const uint32_t slot = tb.first + (valid ? t : 0u);
-    const float4 me = a.xm[slot];
-    const float ix = me.x, iy = me.y, iz = (D == 3) ? me.z : 0.0f;
+    const uint32_t pslot = p_first + (valid ? t : 0u);
+    const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot >> 1) * 8u + (pslot & 1u);
+    float ix = 0.f, iy = 0.f, iz = 0.f;
+    if (p_count) { ix = xf[0]; iy = xf[2]; if (D == 3) iz = xf[4]; }
     const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-    double ox = 0.0, oy = 0.0, oz = 0.0;
-    float* const tf = reinterpret_cast<float*>(tile);
-    const unsigned wr = (tid >> 1) * 8u + (tid & 1u);      // source tid = half (tid & 1) of pair tid / 2
-    // the lane groups stride through the tile's pairs P at a time: the last trip may reach up to P - 1 pairs past the
-    // tile -- massless bodies far away, staged once
-    if (tid < 2u * (unsigned)kMaxLanesPerTarget)
-        tile[BLOCK + tid] = (tid & 1u) ? make_float4((D == 3) ? 1.0e18f : 0.0f, (D == 3) ? 1.0e18f : 0.0f, 0.f, 0.f) : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 1.0e18f);
-    const uint32_t e1 = a.list_offsets[tb.leaf + 1];
-    // the list in chunks of BLOCK entries (one chunk for every list the reference's trees produce); all workgroup-uniform
-    for (uint32_t e0 = a.list_offsets[tb.leaf]; e0 < e1; e0 += (uint32_t)BLOCK) {
-        const unsigned n_ent = (e1 - e0 < (uint32_t)BLOCK) ? (unsigned)(e1 - e0) : (unsigned)BLOCK;
-        uint32_t first = 0, len = 0;
-        if (tid < n_ent) {
-            const uint32_t s = a.list_sources[e0 + tid];
-            first = a.leaf_offsets[s];
-            len = a.leaf_offsets[s + 1] - first;
+    // No special case of any law can apply to a pair of this wave (comment at the top of the file): every target of the piece lies
+    // outside the close set, and m 2^94 stays finite for every mass.  The lanes left over hold the piece's first target.
+    const bool in_close_set = !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
+    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
+    Sums<D> S;
+    __shared__ double osum[3][kThreads];
+    osum[0][tid] = 0.0; osum[1][tid] = 0.0; osum[2][tid] = 0.0;   // only this lane touches them until the closing barrier
+    S.o = &osum[0][tid];
+    // a pad pair: unit {x,x,y,y} = far, unit {z,z,m,m} = {far (0 in 2D), 0}; selected by component (an indexed pair of constants ends up in scratch)
+    const bool odd_unit = (tid & 1u) != 0u;
+    const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
+    const float4 pad_unit = make_float4(pad_xy, pad_xy, pad_zm, pad_zm);
+    // the ops in chunks of kMaxOps (one chunk for every list the reference's trees produce); all workgroup-uniform
+    for (uint32_t c0 = 0; c0 < op_n; c0 += (uint32_t)kMaxOps) {
+        const unsigned n_ops = (op_n - c0 < (uint32_t)kMaxOps) ? (unsigned)(op_n - c0) : (unsigned)kMaxOps;
+        __syncthreads();                                       // the previous chunk's last tile and tables are done with
+        if (tid < n_ops) {
+            const CopyOp o = a.ops[op_lo + c0 + tid];
+            op_end[tid] = o.end;
+            op_base[tid] = o.base;
         }
-        __syncthreads();                                   // the previous chunk's last tile and tables are done with
-        seg_end[tid] = len;
+        const uint32_t u_begin = c0 ? a.ops[op_lo + c0 - 1u].end : 0u;
+        const uint32_t u_end = a.ops[op_lo + c0 + n_ops - 1u].end;
         __syncthreads();
-        for (unsigned d = 1; d < (unsigned)BLOCK; d <<= 1) {   // inclusive prefix sum (Hillis-Steele)
-            const uint32_t add = (tid >= d) ? seg_end[tid - d] : 0u;
-            __syncthreads();
-            seg_end[tid] += add;
-            __syncthreads();
-        }
-        const uint32_t my_end = seg_end[tid];
-        seg_first[tid] = first - (my_end - len);
-        __syncthreads();
-        const uint32_t total = seg_end[BLOCK - 1];         // bodies in this chunk's stream
-        // Tiles of the stream, software-pipelined: the next tile's global loads are issued before the current tile is
-        // consumed, so their latency hides behind the pair loop.
-        unsigned k = 0;                                    // this lane's list entry; only ever moves forward
-        auto load = [&](uint32_t pos) -> float4 {
-            // positions past the stream's end stage a massless body far away: it pads the last tile to whole pairs and
-            // contributes exactly 0 under every law (r^2 ~ 1e36 is finite in fp32, w = 0 * r^-4)
-            float4 v = make_float4(1.0e18f, 1.0e18f, (D == 3) ? 1.0e18f : 0.0f, 0.f);
-            if (pos < total) {
-                while (pos >= seg_end[k]) ++k;             // empty leaves are stepped over here as well
-                const uint32_t j = seg_first[k] + pos;
-                v = a.xm[j];
+        unsigned k = 0;                                        // this lane's cursor in the chunk's ops; only ever moves forward
+        // kUnitsPerLane named registers (an indexed array ends up in scratch)
+        float4 nxt0 = pad_unit, nxt1 = pad_unit, nxt2 = pad_unit, nxt3 = pad_unit;
+        auto load1 = [&](const uint32_t u, float4& v) {
+            if (u < u_end) {
+                while (u >= op_end[k]) ++k;
+                v = a.xp[op_base[k] + u];
             }
-            return v;
         };
-        float4 nxt = load(tid);
-        // fp32 sums run over up to 256 terms per lane (as in the brute-force kernel's tiles) before they are flushed into
-        // the fp64 accumulators: with P lanes per target that is several tiles -- a flush per 64-body tile was 6
-        // conversions and 6 fp64 additions against as little as 8 trips of pair arithmetic
-        f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
-        unsigned pending = 0;                                  // terms in the fp32 sums since the last flush
-        for (uint32_t pos0 = 0; pos0 < total; pos0 += (uint32_t)BLOCK) {
-            const uint32_t cur = (total - pos0 < (uint32_t)BLOCK) ? total - pos0 : (uint32_t)BLOCK;
-            __syncthreads();                                   // previous tile fully consumed
-            tf[wr] = nxt.x; tf[wr + 2] = nxt.y; tf[wr + 4] = nxt.z; tf[wr + 6] = nxt.w;
+        auto load = [&](const uint32_t u0) {
+            load1(u0 + tid, nxt0);
+            load1(u0 + (uint32_t)kThreads + tid, nxt1);
+            if (kUnitsPerLane > 2) {
+                load1(u0 + 2u * (uint32_t)kThreads + tid, nxt2);
+                load1(u0 + 3u * (uint32_t)kThreads + tid, nxt3);
+            }
+        };
+        load(u_begin);
+        for (uint32_t u0 = u_begin; u0 < u_end; u0 += (uint32_t)kTileUnits) {
+            const unsigned cur = (u_end - u0 < (uint32_t)kTileUnits) ? (unsigned)(u_end - u0) : (unsigned)kTileUnits;   // even
+            __syncthreads();                                   // previous tile fully consumed by both waves
+            if (tid < cur) tile[tid] = nxt0;
+            if ((unsigned)kThreads + tid < cur) tile[(unsigned)kThreads + tid] = nxt1;
+            if (kUnitsPerLane > 2) {
+                if (2u * (unsigned)kThreads + tid < cur) tile[2u * (unsigned)kThreads + tid] = nxt2;
+                if (3u * (unsigned)kThreads + tid < cur) tile[3u * (unsigned)kThreads + tid] = nxt3;
+            }
+            if (tid < 2u * (unsigned)kPadPairs) tile[cur + tid] = pad_unit;
             __syncthreads();
-            if (pos0 + (uint32_t)BLOCK < total) nxt = load(pos0 + (uint32_t)BLOCK + tid);   // in flight while this tile is consumed
-            // A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips
-            // i == j by index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-            // every lane makes the same number of trips: the lanes past the stream's end staged pad bodies, so every pair of
-            // the tile up to a multiple of P past the last real one is real or pad, never stale
-            const unsigned trips = (((cur + 1u) >> 1) + P - 1u) / P;
-            const float4* src = tile + 2u * g;
-            // one source pair {A, B} against this lane's target: d, r^2, then the weights (plain form, or the guarded one
-            // when the wave's vote says some lane is below the law's threshold) and the accumulation
-            struct Pair { f2 dx, dy, dz, r2, sm; };
-            auto geometry = [&](const float4 A, const float4 B) -> Pair {
-                Pair q;
-                q.sm = f2{B.z, B.w};
-                q.dx = f2{A.x, A.y} - ix2;
-                q.dy = f2{A.z, A.w} - iy2;
-                q.dz = (D == 3) ? f2{B.x, B.y} - iz2 : f2{0.f, 0.f};
-                q.r2 = q.dx * q.dx;
-                q.r2 = __builtin_elementwise_fma(q.dy, q.dy, q.r2);
-                if (D == 3) q.r2 = __builtin_elementwise_fma(q.dz, q.dz, q.r2);
-                return q;
-            };
-            auto special = [&](const Pair& q) -> unsigned long long {
-                return __builtin_amdgcn_ballot_w64(q.r2.x < law_special_below<LAW>()) | __builtin_amdgcn_ballot_w64(q.r2.y < law_special_below<LAW>());
-            };
-            auto guarded = [&](const Pair& q) -> f2 {
-                float ra = q.r2.x, rb = q.r2.y;
-                asm volatile("" : "+v"(ra), "+v"(rb));   // keeps the guarded form's compares in this (rare) branch: hipcc hoists them otherwise
-                return f2{leaf_weight<D, LAW>(ra, q.sm.x, q.dx.x, q.dy.x, q.dz.x), leaf_weight<D, LAW>(rb, q.sm.y, q.dx.y, q.dy.y, q.dz.y)};
-            };
-            auto plain = [&](const Pair& q) -> f2 {
-                f2 w = {__builtin_amdgcn_rcpf(q.r2.x), __builtin_amdgcn_rcpf(q.r2.y)};
-                w = w * w;
-                return w * q.sm;
-            };
-            auto add = [&](const Pair& q, const f2 w) {
-                ax = __builtin_elementwise_fma(w, q.dx, ax);
-                ay = __builtin_elementwise_fma(w, q.dy, ay);
-                if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
-            };
-            unsigned it = 0;
-            for (; it + 1u < trips; it += 2u, src += 4u * P) {   // two source pairs per trip: one vote, independent chains
-                const Pair q0 = geometry(src[0], src[1]), q1 = geometry(src[2u * P], src[2u * P + 1u]);
-                f2 w0, w1;
-                if (__builtin_expect((special(q0) | special(q1)) != 0ull, 0)) { w0 = guarded(q0); w1 = guarded(q1); }     // wave-uniform, rare
-                else { w0 = plain(q0); w1 = plain(q1); }
-                add(q0, w0);
-                add(q1, w1);
-            }
-            if (it < trips) {
-                const Pair q0 = geometry(src[0], src[1]);
-                const f2 w0 = __builtin_expect(special(q0) != 0ull, 0) ? guarded(q0) : plain(q0);
-                add(q0, w0);
-            }
-            pending += 2u * trips;
-            if (pending + (unsigned)BLOCK > 256u || pos0 + (uint32_t)BLOCK >= total) {   // workgroup-uniform
-                ox += (double)ax.x + (double)ax.y;
-                oy += (double)ay.x + (double)ay.y;
-                oz += (double)az.x + (double)az.y;
-                ax = ay = az = f2{0.f, 0.f};
-                pending = 0;
+            if (u0 + (uint32_t)kTileUnits < u_end) load(u0 + (uint32_t)kTileUnits);   // in flight while this tile is consumed
+            if (p_count) {                                     // wave-uniform
+                const unsigned pairs = cur >> 1;
+                const unsigned T = (((pairs + P - 1u) * inv_P) >> 16) | 1u;
+                const float4* s = tile + 2u * g * T;
+                if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
+                else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
             }
         }
     }
-    if (P > 1u) {                                              // block-uniform
-        __syncthreads();
-        red[0][tid] = ox; red[1][tid] = oy; red[2][tid] = oz;
-        __syncthreads();
-        if (g == 0u)
-            for (unsigned q = 1; q < P; ++q) { ox += red[0][q * W + t]; oy += red[1][q * W + t]; oz += red[2][q * W + t]; }
-    }
+    S.flush();
+    // the lane groups' fp64 sums meet in LDS, in group order (deterministic)
+    __syncthreads();
     if (valid && g == 0u) {
-        a.acc[slot] = ox;
-        a.acc[(size_t)a.slots + slot] = oy;
-        if (D == 3) a.acc[2 * (size_t)a.slots + slot] = oz;
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+        const unsigned l0 = (tid & ~63u) + t;
+        for (unsigned q = 0; q < P; ++q) { ox += osum[0][l0 + q * W]; oy += osum[1][l0 + q * W]; oz += osum[2][l0 + q * W]; }
+        a.acc[pslot] = ox;
+        a.acc[(size_t)a.pslots + pslot] = oy;
+        if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
     }
 }
 
-// staged Body<D> AoS fp64 (host order) -> leaf-ordered {x, y, z, m} fp32
+// staged Body<D> AoS fp64 (host order) -> leaf-ordered source pairs, fp32; a padded slot without a body is massless and far away
 __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restrict__ raw, size_t stride_d, int dim,
-                                                          const uint32_t* __restrict__ leaf_bodies, uint32_t slots,
-                                                          float4* __restrict__ xm) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= slots) return;
-    const double* __restrict__ b = raw + (size_t)leaf_bodies[s] * stride_d;
-    xm[s] = make_float4((float)b[0], (float)b[1], dim == 3 ? (float)b[2] : 0.0f, (float)b[2 * dim]);
+                                                          const uint32_t* __restrict__ pslot_body, uint32_t pslots, float* __restrict__ xp,
+                                                          uint32_t* __restrict__ max_mass_bits) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t body = p < pslots ? pslot_body[p] : 0xffffffffu;
+    float x = kFar, y = kFar, z = dim == 3 ? kFar : 0.0f, m = 0.0f;
+    if (body != 0xffffffffu) {
+        const double* __restrict__ b = raw + (size_t)body * stride_d;
+        x = (float)b[0]; y = (float)b[1]; z = dim == 3 ? (float)b[2] : 0.0f; m = (float)b[2 * dim];
+    }
+    // largest |mass| of the call: non-negative fp32 order like their bit patterns, a NaN above them all
+    uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_fabsf(m));
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)mb, d);
+        mb = other > mb ? other : mb;
+    }
+    if ((threadIdx.x & 63u) == 0u && mb) atomicMax(max_mass_bits, mb);
+    if (p >= pslots) return;
+    float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
+    o[0] = x; o[2] = y; o[4] = z; o[6] = m;
 }
 
 // forces_out[body] = sign * (G m_body) * acc[slot]   (fp64; every body belongs to at most one leaf)
 __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restrict__ acc, const double* __restrict__ raw, size_t stride_d,
-                                                           int dim, const uint32_t* __restrict__ leaf_bodies, uint32_t slots, double signedG,
+                                                           int dim, const uint32_t* __restrict__ pslot_body, uint32_t pslots, double signedG,
                                                            double* __restrict__ forces) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= slots) return;
-    const uint32_t body = leaf_bodies[s];
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= pslots) return;
+    const uint32_t body = pslot_body[p];
+    if (body == 0xffffffffu) return;
     const double gm = signedG * raw[(size_t)body * stride_d + 2 * dim];
-    for (int k = 0; k < dim; ++k) forces[(size_t)body * dim + k] = gm * acc[(size_t)k * slots + s];
+    for (int k = 0; k < dim; ++k) forces[(size_t)body * dim + k] = gm * acc[(size_t)k * pslots + p];
 }
 
 typedef void (*LeafKernel)(LeafArgs);
-template <int BLOCK>
 LeafKernel pick(int dim, int law) {
     static const LeafKernel table[2][3] = {
-        {leaf_pair_kernel<2, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, BLOCK>},
-        {leaf_pair_kernel<3, NBX_LAW_BRUTE, BLOCK>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, BLOCK>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, BLOCK>}};
+        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
     return table[dim - 2][law];
+}
+
+// How a run of c targets (<= 128) is cut into the two pieces of a workgroup: the cut that keeps the most lanes busy
+// (a piece of c runs min(64 / c, 8) lanes per target and takes 1 / that of the source pairs' trips), the more even one among equals.
+struct PieceCut { uint8_t c1[129]; };
+PieceCut best_cuts() {
+    PieceCut r;
+    auto trips = [](int c) -> double {
+        if (c == 0) return 0.0;
+        int lanes = 64 / c;
+        if (lanes > kMaxLanesPerTarget) lanes = kMaxLanesPerTarget;
+        return 1.0 / lanes;
+    };
+    r.c1[0] = 0;
+    for (int c = 1; c <= 128; ++c) {
+        double best = 1e30, best_max = 1e30;
+        int arg = c <= 64 ? c : 64;
+        for (int a = (c > 64 ? c - 64 : 0); a <= c && a <= 64; ++a) {
+            const double ta = trips(a), tb = trips(c - a);
+            const double sum = ta + tb, mx = ta > tb ? ta : tb;
+            if (sum < best - 1e-12 || (sum < best + 1e-12 && mx < best_max - 1e-12)) { best = sum; best_max = mx; arg = a; }
+        }
+        r.c1[c] = (uint8_t)arg;
+    }
+    return r;
 }
 
 struct DeviceBuffers {   // frees whatever was allocated when the call leaves, on every path
@@ -344,30 +459,70 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
-    size_t nonempty = 0;
-    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
-    // block size by the mean leaf: up to 80 bodies per leaf one wave64 per block wastes fewer lanes than two
-    const uint32_t block = (nonempty && slots / nonempty <= 80) ? (uint32_t)kLeafBlockSmall : (uint32_t)kLeafBlock;
-    // Target blocks.  A block of c targets runs floor(block / c) lanes per target (kernel), so c just above block / 2 wastes
-    // almost half the lanes: such a piece is cut in two when that fills the lanes better by more than the cost of staging
-    // the source stream a second time (~15 %): 33..42 targets in a wave64 become two blocks at 3 lanes per target.
-    auto lane_use = [&](uint32_t c) -> double {
-        uint32_t lanes = block / c;
-        if (lanes > (uint32_t)kMaxLanesPerTarget) lanes = (uint32_t)kMaxLanesPerTarget;
-        return (double)(c * lanes) / (double)block;
-    };
-    std::vector<TargetBlock> blocks;
-    for (size_t l = 0; l < n_leaves; ++l)
-        for (uint32_t f = leaf_offsets[l]; f < leaf_offsets[l + 1]; f += block) {
-            const uint32_t c = (leaf_offsets[l + 1] - f < block) ? leaf_offsets[l + 1] - f : block;
-            const uint32_t half = (c + 1) / 2;
-            if (c >= 2 && lane_use(half) > 1.15 * lane_use(c)) {
-                blocks.push_back(TargetBlock{(uint32_t)l, f, half});
-                blocks.push_back(TargetBlock{(uint32_t)l, f + half, c - half});
-            } else {
-                blocks.push_back(TargetBlock{(uint32_t)l, f, c});
-            }
+    // ---- the layout the kernel follows (comment at the top of the file) ----
+    // padded slots: a leaf of odd size gets one more slot, so that every leaf is a run of whole source pairs
+    std::vector<uint32_t> unit_off(n_leaves + 1);
+    {
+        uint64_t u = 0;
+        for (size_t l = 0; l < n_leaves; ++l) {
+            unit_off[l] = (uint32_t)u;
+            u += (uint64_t)((leaf_offsets[l + 1] - leaf_offsets[l] + 1u) & ~1u);
         }
+        if (u > 0xfffffff0ull) return fail(NBX_ERR_INVALID, "too many bodies / leaves");
+        unit_off[n_leaves] = (uint32_t)u;
+    }
+    const size_t pslots = unit_off[n_leaves];
+    std::vector<uint32_t> pslot_body(pslots, 0xffffffffu);
+    for (size_t l = 0; l < n_leaves; ++l)
+        for (uint32_t s = leaf_offsets[l]; s < leaf_offsets[l + 1]; ++s) pslot_body[unit_off[l] + (s - leaf_offsets[l])] = leaf_bodies[s];
+    // copy ops: the source list of each leaf as runs of consecutive units (neighbours in leaf order merged), empty leaves dropped
+    std::vector<CopyOp> ops;
+    std::vector<uint32_t> op_off(n_leaves + 1);
+    ops.reserve(n_list / 2 + 16);
+    for (size_t l = 0; l < n_leaves; ++l) {
+        op_off[l] = (uint32_t)ops.size();
+        uint64_t stream = 0;        // units so far
+        uint32_t run_first = 0, run_len = 0;
+        auto close_run = [&]() {
+            if (!run_len) return;
+            stream += run_len;
+            ops.push_back(CopyOp{(uint32_t)stream, run_first - (uint32_t)(stream - run_len)});
+            run_len = 0;
+        };
+        for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e) {
+            const uint32_t s = list_sources[e];
+            const uint32_t first = unit_off[s], len = unit_off[s + 1] - unit_off[s];
+            if (!len) continue;
+            if (run_len && first == run_first + run_len) run_len += len;
+            else { close_run(); run_first = first; run_len = len; }
+            if (stream + run_len > 0xfffff000ull) return fail(NBX_ERR_INVALID, "a leaf's source list names more than 2^32 bodies");
+        }
+        close_run();
+        if (ops.size() > 0xfffffff0ull) return fail(NBX_ERR_INVALID, "source lists too long");
+    }
+    op_off[n_leaves] = (uint32_t)ops.size();
+    // workgroups: 128 targets of a leaf at most, cut into the two waves' pieces
+    static const PieceCut cuts = best_cuts();
+    std::vector<LeafBlock> blocks;
+    blocks.reserve(n_leaves);
+    for (size_t l = 0; l < n_leaves; ++l) {
+        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
+        if (!c) continue;
+        const uint32_t groups = (c + 127u) / 128u;
+        uint32_t f = unit_off[l];
+        for (uint32_t gi = 0; gi < groups; ++gi) {
+            const uint32_t share = c / groups + (gi < c % groups ? 1u : 0u);   // <= 128
+            const uint32_t c1 = cuts.c1[share];
+            LeafBlock b;
+            b.op_lo = op_off[l];
+            b.op_n = op_off[l + 1] - op_off[l];
+            b.pad_[0] = b.pad_[1] = 0;
+            b.piece[0] = Piece{f, c1};
+            b.piece[1] = Piece{f + c1, share - c1};
+            blocks.push_back(b);
+            f += share;
+        }
+    }
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
@@ -375,49 +530,57 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(nbx::take_stream(device, &d.stream));
     NBX_HIP_TRY(hipEventCreate(&d.ev0));
     NBX_HIP_TRY(hipEventCreate(&d.ev1));
-    // one allocation for the call's ten device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
-    const size_t sizes[10] = {n * stride_bytes, slots * sizeof(float4), 0, (size_t)dim * slots * sizeof(double),
-                              n * (size_t)dim * sizeof(double), (n_leaves + 1) * sizeof(uint32_t), slots * sizeof(uint32_t),
-                              (n_leaves + 1) * sizeof(uint32_t), n_list * sizeof(uint32_t), blocks.size() * sizeof(TargetBlock)};
-    size_t offs[10], total_bytes = 0;
-    for (int i = 0; i < 10; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
+    // one allocation for the call's device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
+    const size_t sizes[8] = {n * stride_bytes, pslots * sizeof(float4), (size_t)dim * pslots * sizeof(double), n * (size_t)dim * sizeof(double),
+                             pslots * sizeof(uint32_t), ops.size() * sizeof(CopyOp), blocks.size() * sizeof(LeafBlock), sizeof(uint32_t)};
+    size_t offs[8], total_bytes = 0;
+    for (int i = 0; i < 8; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
     char* arena = nullptr;
     NBX_HIP_TRY(hipMalloc((void**)&arena, total_bytes));
     d.ptrs.push_back(arena);
     double* raw = reinterpret_cast<double*>(arena + offs[0]);
-    float4* xm = reinterpret_cast<float4*>(arena + offs[1]);
-    double* acc = reinterpret_cast<double*>(arena + offs[3]);
-    double* dforces = reinterpret_cast<double*>(arena + offs[4]);
-    uint32_t* d_lo = reinterpret_cast<uint32_t*>(arena + offs[5]);
-    uint32_t* d_lb = reinterpret_cast<uint32_t*>(arena + offs[6]);
-    uint32_t* d_so = reinterpret_cast<uint32_t*>(arena + offs[7]);
-    uint32_t* d_ss = reinterpret_cast<uint32_t*>(arena + offs[8]);
-    TargetBlock* d_blocks = reinterpret_cast<TargetBlock*>(arena + offs[9]);
+    float4* xp = reinterpret_cast<float4*>(arena + offs[1]);
+    double* acc = reinterpret_cast<double*>(arena + offs[2]);
+    double* dforces = reinterpret_cast<double*>(arena + offs[3]);
+    uint32_t* d_pb = reinterpret_cast<uint32_t*>(arena + offs[4]);
+    CopyOp* d_ops = reinterpret_cast<CopyOp*>(arena + offs[5]);
+    LeafBlock* d_blocks = reinterpret_cast<LeafBlock*>(arena + offs[6]);
+    uint32_t* d_max_mass = reinterpret_cast<uint32_t*>(arena + offs[7]);
     NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
-    NBX_HIP_TRY(hipMemcpyAsync(d_lo, leaf_offsets, (n_leaves + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    NBX_HIP_TRY(hipMemcpyAsync(d_lb, leaf_bodies, slots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    NBX_HIP_TRY(hipMemcpyAsync(d_so, list_offsets, (n_leaves + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    if (n_list) NBX_HIP_TRY(hipMemcpyAsync(d_ss, list_sources, n_list * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(TargetBlock), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_pb, pslot_body.data(), pslots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    if (!ops.empty()) NBX_HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(CopyOp), hipMemcpyHostToDevice, d.stream));
+    NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(LeafBlock), hipMemcpyHostToDevice, d.stream));
     NBX_HIP_TRY(hipMemsetAsync(dforces, 0, n * (size_t)dim * sizeof(double), d.stream));
+    NBX_HIP_TRY(hipMemsetAsync(d_max_mass, 0, sizeof(uint32_t), d.stream));
     (void)hipGetLastError();
-    const unsigned gs = (unsigned)((slots + 255) / 256);
-    hipLaunchKernelGGL(leaf_gather_kernel, dim3(gs), dim3(256), 0, d.stream, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots, xm);
+    const unsigned gs = (unsigned)((pslots + 255) / 256);
+    hipLaunchKernelGGL(leaf_gather_kernel, dim3(gs), dim3(256), 0, d.stream, raw, stride_bytes / sizeof(double), dim, d_pb, (uint32_t)pslots,
+                       reinterpret_cast<float*>(xp), d_max_mass);
     NBX_HIP_TRY(hipGetLastError());
     LeafArgs a;
-    a.xm = xm; a.slots = (uint32_t)slots; a.leaf_offsets = d_lo; a.list_offsets = d_so; a.list_sources = d_ss;
-    a.blocks = d_blocks; a.acc = acc;
-    NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(block == (uint32_t)kLeafBlockSmall ? pick<kLeafBlockSmall>(dim, law) : pick<kLeafBlock>(dim, law),
-                       dim3((unsigned)blocks.size()), dim3(block), 0, d.stream, a);
-    NBX_HIP_TRY(hipGetLastError());
+    a.xp = xp; a.pslots = (uint32_t)pslots; a.ops = d_ops; a.blocks = d_blocks; a.acc = acc; a.max_mass_bits = d_max_mass;
+    // NBX_LEAF_TIMING_REPS=R (a measurement aid, 2 <= R <= 1000): the pair kernel is launched R times back to back -- it writes the
+    // same sums every time -- and kernel_ms reports the mean of the second half of the launches: the kernel's duration once the
+    // clocks have come up from idle (2.3 GHz after ~30 ms of load), as they are inside a running tree code.  The single launch of
+    // an ordinary call follows the call's host work and copies and runs at ~2.05 GHz.
+    int reps = 1;
+    if (const char* e = getenv("NBX_LEAF_TIMING_REPS")) { reps = atoi(e); if (reps < 1) reps = 1; if (reps > 1000) reps = 1000; }
+    const int timed_from = reps / 2;
+    for (int r = 0; r < reps; ++r) {
+        if (r == timed_from) NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
+        hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kThreads), 0, d.stream, a);
+        NBX_HIP_TRY(hipGetLastError());
+    }
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
-    hipLaunchKernelGGL(leaf_scatter_kernel, dim3(gs), dim3(256), 0, d.stream, acc, raw, stride_bytes / sizeof(double), dim, d_lb, (uint32_t)slots,
+    hipLaunchKernelGGL(leaf_scatter_kernel, dim3(gs), dim3(256), 0, d.stream, acc, raw, stride_bytes / sizeof(double), dim, d_pb, (uint32_t)pslots,
                        signedG, dforces);
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipMemcpyAsync(forces_out, dforces, n * (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, d.stream));
     NBX_HIP_TRY(hipStreamSynchronize(d.stream));
-    if (kernel_ms) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, d.ev0, d.ev1));
+    if (kernel_ms) {
+        NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, d.ev0, d.ev1));
+        *kernel_ms /= (float)(reps - timed_from);
+    }
     return NBX_OK;
 }

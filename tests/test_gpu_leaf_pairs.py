@@ -127,10 +127,10 @@ def test_ragged_structure_and_close_pairs(nbx, oracle):
 @pytest.mark.parametrize("dim", (3, 2))
 @pytest.mark.parametrize("big", (False, True))
 def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
-    """Target leaves of every size from 1 to 70 (small: wave64 blocks) or 1 to 258 in steps of 3 (big: 128-lane blocks), so
-    that every lanes-per-target count, every split of a piece in two and every partly filled last tile occurs; source lists
-    of 1 to 300 entries with repeats and empty leaves in them (longer than one block of list entries: chunked), odd and even
-    stream lengths; all three laws."""
+    """Target leaves of every size from 1 to 70 or 1 to 258 in steps of 3 (big: up to three workgroups per leaf), so that every
+    lanes-per-target count, every cut of a leaf into the two waves' pieces and every partly filled last tile occurs; source
+    lists of 1 to 300 entries in random order, with repeats and empty leaves in them (more copy runs than the kernel holds in
+    LDS at a time: chunked; streams of several tiles), odd and even leaf sizes (padded source pairs); all three laws."""
     sizes = list(range(1, 71)) if not big else list(range(1, 260, 3))
     sizes += [0, 0]                                                  # two empty leaves, also as sources
     rng = np.random.default_rng(90 + dim + 2 * big)
@@ -152,9 +152,44 @@ def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
     so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
     ss = np.concatenate(lists)
     leaves = (lo, lb, so, ss)
-    assert (np.mean([s for s in sizes if s]) > 80) == big           # which block size the library picks
     for law, name in LAWS:
         _check(nbx, oracle, b, leaves, law, f"every block shape, law {name}, D={dim}, big={big}")
+
+
+@pytest.mark.parametrize("dim", (3, 2))
+def test_unguarded_and_guarded_waves(nbx, oracle, dim):
+    """The pair loop without any compare runs for a wave whose targets all lie outside the close set (every |coordinate| >= 2^14,
+    csrc/nbx_internal.h) while no mass exceeds 1e10; every other wave takes the guarded loop.  Both must give the law's result:
+    (a) the reference generator's box (coordinates up to 1e7: nearly every wave unguarded) with identical positions planted --
+    inside one leaf and across two leaves -- and every body meeting itself in its own leaf;
+    (b) the same bodies with one mass above the bound: every wave guarded, same forces up to that body's own contribution;
+    (c) a grid cell that straddles the close set's boundary: guarded and unguarded waves side by side."""
+    n = 6000
+    b = oracle.generate(120 + dim, n, dim)
+    b[:, :dim] = np.abs(b[:, :dim]) + 20000.0                         # every body outside the close set
+    leaves = nbx.leaves.uniform_grid_leaves(oracle.round_inputs_to_f32(b), dim, 2 if dim == 3 else 3)
+    lo, lb, so, ss = leaves
+    first, second = lb[lo[0]], lb[lo[0] + 1]                         # two bodies of leaf 0 ...
+    other = lb[lo[1]]                                                # ... and one of its neighbour
+    b[second, :dim] = b[first, :dim]
+    b[other, :dim] = b[first, :dim]                                  # (stays in leaf 1's list: a pair across leaves at r^2 = 0)
+    b = oracle.round_inputs_to_f32(b)
+    for law, name in LAWS:
+        f, _ = _check(nbx, oracle, b, leaves, law, f"unguarded waves, law {name}, D={dim}")
+        heavy = b.copy()
+        heavy[lb[lo[2]], -1] = 3.0e10                                # above kFastMaxMass: the guarded loop everywhere
+        fh, _ = _check(nbx, oracle, heavy, leaves, law, f"guarded by a heavy mass, law {name}, D={dim}")
+        blind = [t for t in range(lo.size - 1) if 2 not in ss[so[t]:so[t + 1]]]     # leaves whose lists do not name leaf 2
+        far = np.concatenate([lb[lo[t]:lo[t + 1]] for t in blind])
+        S = oracle.leaf_pair_magnitude_sums(b, leaves, law)[far]
+        gap = np.linalg.norm(f[far] - fh[far], axis=1)
+        assert far.size and (gap <= 1.0e-6 * S).all(), f"the two loops must agree to fp32 rounding where the heavy body is not a source: {(gap / S).max():.2e}"
+    c = oracle.generate(130 + dim, n, dim)
+    c[:, :dim] = c[:, :dim] / 1.0e7 * 60000.0                        # a box of 6e4: about half of the bodies inside the close set
+    c = oracle.round_inputs_to_f32(c)
+    cl = nbx.leaves.uniform_grid_leaves(c, dim, 2 if dim == 3 else 3)
+    for law, name in LAWS:
+        _check(nbx, oracle, c, cl, law, f"guarded and unguarded waves mixed, law {name}, D={dim}")
 
 
 def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):

@@ -15,13 +15,33 @@ sizes = np.diff(lo).astype(np.int64)
 src = np.add.reduceat(sizes[ss], so[:-1])          # bodies on each leaf's list (every list here is non-empty)
 pairs = int((sizes * src).sum())
 print(f"N={n}, {sizes.size} leaves (mean {sizes.mean():.1f}, max {sizes.max()}), {pairs:.3e} pair terms", flush=True)
-for law, name in ((nbx.LAW_BRUTE, "brute"), (nbx.LAW_TREE_LEAF, "tree_leaf"), (nbx.LAW_FMM_P2P, "fmm_p2p")):
+def timed(law, reps):
+    """Best kernel time and best whole-call time of three calls; reps > 1: the library launches the kernel that many times back to
+    back and reports the mean of the second half (NBX_LEAF_TIMING_REPS, csrc/leaf_pair_kernel.hip)."""
+    if reps > 1:
+        os.environ["NBX_LEAF_TIMING_REPS"] = str(reps)
+    else:
+        os.environ.pop("NBX_LEAF_TIMING_REPS", None)
     best, wall = 1e30, 1e30
     for _ in range(3):
         t0 = time.perf_counter()
         _, ms = nbx.leaf_pair_forces_hip(b, *leaves, law=law, return_kernel_ms=True)
         wall = min(wall, (time.perf_counter() - t0) * 1e3)
         best = min(best, ms)
-    tflops = pairs * 20.0 / (best * 1e-3) / 1e12      # 20 flop per pair term, the brute-force path's convention
-    print(f"law {name:9s}: kernel {best:.3f} ms = {pairs / best * 1e3:.3e} pairs/s = {tflops:.1f} TFLOP/s = {tflops / 157.3:.3f} of the MI355X fp32 "
-          f"vector peak;  whole call (validation, H2D, gather, kernel, scatter, D2H) {wall:.2f} ms", flush=True)
+    os.environ.pop("NBX_LEAF_TIMING_REPS", None)
+    return best, wall
+
+
+def rate(ms):
+    tflops = pairs * 20.0 / (ms * 1e-3) / 1e12      # 20 flop per pair term, the brute-force path's convention (SURVEY 8d)
+    return f"{ms:.3f} ms = {pairs / ms * 1e3:.3e} pairs/s = {tflops:.1f} TFLOP/s = {tflops / 157.3:.3f} of the MI355X fp32 vector peak"
+
+
+LAWS = ((nbx.LAW_BRUTE, "brute"), (nbx.LAW_TREE_LEAF, "tree_leaf"), (nbx.LAW_FMM_P2P, "fmm_p2p"))
+cold = {name: timed(law, 1) for law, name in LAWS}              # all of these before any sustained load
+for law, name in LAWS:
+    print(f"law {name:9s}: kernel, one launch after the call's host work and copies (clocks at ~2.05 GHz) {rate(cold[name][0])};  "
+          f"whole call (validation, layout, H2D, gather, kernel, scatter, D2H) {cold[name][1]:.2f} ms", flush=True)
+for law, name in LAWS:
+    warm, _ = timed(law, 300)
+    print(f"law {name:9s}: kernel, mean of launches 151-300 back to back (clocks up, ~2.3 GHz) {rate(warm)}", flush=True)
