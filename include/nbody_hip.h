@@ -102,8 +102,11 @@ int nbx_leapfrog(void* bodies, size_t n, int dim, size_t body_stride_bytes,
  *       NBX_LAW_TREE_LEAF  octree.cpp:105-125 / bvh.cpp:150-176: force += ...; pairs with r^2 < 1e-9 skipped
  *       NBX_LAW_FMM_P2P    fmm_parlay.cpp:992-1020: force += ...; identical positions (|d_k| <= 1e-14) skipped; for
  *                          r^2 < 1e-10 the magnitude uses r^2 + (1e-5)^2 while the direction stays d/|d|
- * forces_out: n x Vector<dim>, zero for bodies in no leaf.  fp32 pair terms on leaf-ordered SoA arrays, fp64 sums;
- * every index array is validated on the host before anything is launched (NBX_ERR_INVALID).  kernel_ms optional. */
+ * forces_out: n x Vector<dim>, zero for bodies in no leaf.  fp32 pair terms on leaf-ordered source pairs, fp64 sums;
+ * every index array is validated on the host before anything is launched (NBX_ERR_INVALID).  kernel_ms (optional)
+ * receives the pair kernel's duration (hipEvent).  Measurement aid: with NBX_LEAF_TIMING_REPS=R (2..1000) in the
+ * environment the pair kernel is launched R times back to back (same sums every time) and kernel_ms is the mean of the
+ * second half of the launches -- the duration with the clocks up, which one launch after the call's copies does not see. */
 enum { NBX_LAW_BRUTE = 0, NBX_LAW_TREE_LEAF = 1, NBX_LAW_FMM_P2P = 2 };
 int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
                          const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
@@ -240,7 +243,7 @@ int nbx_ctx_set_law(nbx_ctx* ctx, int law);
  *    Q_i = sum over the 256-source tiles of |tile partial sum|^2 (accumulated by the fast kernel at no measurable cost);
  *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
  *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
- *    calibrated default.  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
+ *    calibrated default (48 in 3D, 64 in 2D).  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
  *    Newtonian law, or a non-fast variant.  At most 1/16 of a shard's targets (at least 16,384) are re-evaluated per force
  *    evaluation; nbx_ctx_refine_stats reports how many the rule selected and how many were re-evaluated. */
 int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);

@@ -33,6 +33,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using namespace nbx;
@@ -64,7 +65,7 @@ struct Piece {
 };
 struct LeafBlock {     // one workgroup; read with scalar loads
     uint32_t op_lo, op_n;   // the leaf's copy ops
-    uint32_t pad_[2];
+    uint32_t pad_[2];       // [0]: host-side sort key
     Piece piece[2];
 };
 static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
@@ -318,6 +319,10 @@ __global__ __launch_bounds__(kThreads) void leaf_pair_kernel(LeafArgs a) {
                 const float4* s = tile + 2u * g * T;
                 if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
                 else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
+#ifdef NBX_LEAF_EXPERIMENT_TWICE   /* timing experiment only: the pair work of every tile twice (wrong sums) */
+                if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
+                else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
+#endif
             }
         }
     }
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restri
         const uint32_t other = (uint32_t)__shfl_xor((int)mb, d);
         mb = other > mb ? other : mb;
     }
-    if ((threadIdx.x & 63u) == 0u && mb) atomicMax(max_mass_bits, mb);
+    // one lane per wave, and only while the wave's maximum is above what is already there (16,384 atomics on one word cost 0.15 ms)
+    if ((threadIdx.x & 63u) == 0u && mb > __atomic_load_n(max_mass_bits, __ATOMIC_RELAXED)) atomicMax(max_mass_bits, mb);
     if (p >= pslots) return;
     float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
     o[0] = x; o[2] = y; o[4] = z; o[6] = m;
@@ -472,9 +478,12 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         unit_off[n_leaves] = (uint32_t)u;
     }
     const size_t pslots = unit_off[n_leaves];
-    std::vector<uint32_t> pslot_body(pslots, 0xffffffffu);
-    for (size_t l = 0; l < n_leaves; ++l)
-        for (uint32_t s = leaf_offsets[l]; s < leaf_offsets[l + 1]; ++s) pslot_body[unit_off[l] + (s - leaf_offsets[l])] = leaf_bodies[s];
+    std::vector<uint32_t> pslot_body(pslots);              // body of each padded slot, 0xffffffff for a leaf's pad
+    for (size_t l = 0; l < n_leaves; ++l) {
+        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
+        if (c) memcpy(&pslot_body[unit_off[l]], leaf_bodies + leaf_offsets[l], (size_t)c * sizeof(uint32_t));
+        if (c & 1u) pslot_body[unit_off[l] + c] = 0xffffffffu;
+    }
     // copy ops: the source list of each leaf as runs of consecutive units (neighbours in leaf order merged), empty leaves dropped
     std::vector<CopyOp> ops;
     std::vector<uint32_t> op_off(n_leaves + 1);
@@ -519,9 +528,30 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
             b.pad_[0] = b.pad_[1] = 0;
             b.piece[0] = Piece{f, c1};
             b.piece[1] = Piece{f + c1, share - c1};
+            {   // how long the workgroup will run: the slower wave's trips over the leaf's stream (sort key below)
+                auto lanes = [](uint32_t c) -> uint32_t { const uint32_t p = c ? 64u / c : (uint32_t)kMaxLanesPerTarget; return p > (uint32_t)kMaxLanesPerTarget ? (uint32_t)kMaxLanesPerTarget : p; };
+                const uint32_t stream_units = b.op_n ? ops[b.op_lo + b.op_n - 1].end : 0u;
+                const uint32_t slower = lanes(c1) < lanes(share - c1) ? lanes(c1) : lanes(share - c1);
+                b.pad_[0] = stream_units / slower;
+            }
             blocks.push_back(b);
             f += share;
         }
+    }
+    // Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
+    // short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).
+    // A counting sort over 1024 duration classes, leaf order kept within a class (neighbours share their sources in L2).
+    if (blocks.size() > 1) {
+        uint32_t longest = 1;
+        for (const LeafBlock& b : blocks) if (b.pad_[0] > longest) longest = b.pad_[0];
+        constexpr uint32_t kClasses = 1024;
+        auto cls = [&](const LeafBlock& b) -> uint32_t { return (kClasses - 1u) - (uint32_t)((uint64_t)b.pad_[0] * (kClasses - 1u) / longest); };
+        std::vector<uint32_t> start(kClasses + 1, 0u);
+        for (const LeafBlock& b : blocks) ++start[cls(b) + 1u];
+        for (uint32_t k = 0; k < kClasses; ++k) start[k + 1] += start[k];
+        std::vector<LeafBlock> sorted(blocks.size());
+        for (const LeafBlock& b : blocks) sorted[start[cls(b)]++] = b;
+        blocks.swap(sorted);
     }
 
     NBX_HIP_TRY(hipSetDevice(device));

@@ -13,6 +13,7 @@
 // as "not built", skipped.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <iomanip>
 #include <iostream>
@@ -260,7 +261,9 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
             const double kernel_ms = last_leaf_pair_kernel_ms();
             out << "Time taken: " << seconds << " s  (" << lists.leaves() << " leaves, " << pairs << " pair terms, kernel "
                 << kernel_ms << " ms = " << pairs / (kernel_ms * 1e-3) << " pair terms/s, "
-                << 100.0 * pairs * 20.0 / (kernel_ms * 1e-3) / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair)" << std::endl;
+                << 100.0 * pairs * 20.0 / (kernel_ms * 1e-3) / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair"
+                << (std::getenv("NBX_LEAF_TIMING_REPS") ? "; NBX_LEAF_TIMING_REPS: mean of the second half of that many launches" : "; one launch")
+                << ")" << std::endl;
             print_validation_forces<D>(forces, n, log);
             print_validation_forces<D>(forces, n, std::cout);
             if (!opt.dump.empty()) dump_raw(opt.dump + "_NearField_HIP.f64", forces);

@@ -17,3 +17,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_refine -o bench -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --refine 1e-5 > $R/$O/bench_refine_prof.json 2> $R/$O/prof_refine.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_leaf -o leaf -- python3 $R/tools/time_leaf_pairs.py > $R/$O/time_leaf_pairs.txt 2> $R/$O/prof_leaf.err
 tail -3 $R/$O/time_leaf_pairs.txt
+cd $R
+timeout -k 10 300 python tests/measure/all_bodies_survey.py uniform20_2d > $O/survey_2d.log 2>&1 || { tail -20 $O/survey_2d.log; exit 1; }
+cp gpurun_out/accuracy_all_bodies.jsonl $O/accuracy_after_survey.jsonl
+NBX_LEAF_TIMING_REPS=300 ./nbody_sim -N 1048576 -d 3 -m p --seed 5 2>&1 | grep "Time taken" | tee $O/nbody_sim_near_field.txt
+./nbody_sim -N 1048576 -d 3 -m p --seed 5 2>&1 | grep "Time taken" | tee -a $O/nbody_sim_near_field.txt
