@@ -126,6 +126,34 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
                       f"({nrows*(n_bodies-1):.3e} pair evaluations) in {dt:.2f} s, OMP_NUM_THREADS={threads}", "host": host}
 
 
+def leaf_pair_roofline(device):
+    """The repository's second hand-written kernel family (near-field sums of the tree codes, csrc/leaf_pair_kernel.hip)
+    against the same fp32 roofline, on tools/time_leaf_pairs.py's workload: N = 2^20 bodies in 32^3 grid leaves, 27-cell lists,
+    FMM P2P law.  Not part of the headline metric; a few seconds on rank 0 of a 1-GPU run."""
+    import numpy as np
+    import nbody_amd as nbx
+    n = 1 << 20
+    b = nbx.uniform_bodies(n, 3, 5)
+    leaves = nbx.leaves.uniform_grid_leaves(b, 3, 5)
+    lo, _, so, ss = leaves
+    sizes = np.diff(lo).astype(np.int64)
+    pairs = int((sizes * np.add.reduceat(sizes[ss], so[:-1])).sum())
+    os.environ.pop("NBX_LEAF_TIMING_REPS", None)
+    cold = min(nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_FMM_P2P, device=device, return_kernel_ms=True)[1] for _ in range(2))
+    os.environ["NBX_LEAF_TIMING_REPS"] = "300"
+    try:
+        warm = nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_FMM_P2P, device=device, return_kernel_ms=True)[1]
+    finally:
+        os.environ.pop("NBX_LEAF_TIMING_REPS", None)
+    tflops = lambda ms: pairs * 20.0 / (ms * 1e-3) / 1e12
+    return {"kernel": "leaf_pair_kernel<3, NBX_LAW_FMM_P2P>", "workload": f"N={n}, {sizes.size} grid leaves (mean {sizes.mean():.1f} bodies), 27-cell lists",
+            "pair_terms_per_launch": pairs, "flop_per_pair_term": 20, "bound": "mfma",
+            "bound_detail": "fp32 VALU issue, as for the force kernel (no MFMA instructions)",
+            "achieved": tflops(warm), "peak": 157.3, "unit": "TFLOP/s", "frac": tflops(warm) / 157.3,
+            "kernel_ms": warm, "kernel_ms_means": "mean of launches 151-300 of 300 back to back (NBX_LEAF_TIMING_REPS): clocks up",
+            "one_launch_from_idle_clocks": {"kernel_ms": cold, "achieved": tflops(cold), "frac": tflops(cold) / 157.3}}
+
+
 def _norm(a):
     import numpy as np
     return np.sqrt((a * a).sum(axis=1))
@@ -440,6 +468,11 @@ def main():
         if rank == 0:
             result["accuracy"] = acc
             result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)   # rank 0's host cores; the other ranks wait below
+            if world == 1 and args.dim == 3:
+                try:
+                    result["other_kernels"] = {"leaf_pair": leaf_pair_roofline(local_rank)}
+                except Exception as e:   # never at the expense of the headline line
+                    result["other_kernels"] = {"leaf_pair": f"not measured: {e.__class__.__name__}: {e}"}
     if world > 1:
         dist.barrier()
     if rank == 0:
