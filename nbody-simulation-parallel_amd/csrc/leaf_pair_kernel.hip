@@ -40,8 +40,8 @@ using namespace nbx;
 
 namespace {
 
-constexpr int kWaves = 2;
-constexpr int kThreads = 64 * kWaves;          // two wave64 per workgroup
+constexpr int kWaves = 2;                      // wave64 per workgroup: each owns one piece of the leaf's targets, both stage the tiles
+constexpr int kThreads = 64 * kWaves;
 constexpr int kUnitsPerLane = 4;               // 16-byte units (= bodies) a lane stages per tile (the kernel names that many registers)
 constexpr int kTileUnits = kThreads * kUnitsPerLane;   // 512 bodies = 256 source pairs = 8 KB of LDS
 constexpr int kPadPairs = 16;                  // massless pairs behind the tile's last one: the lane groups' last trips reach up to 2 P - 1 past it
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void leaf_pair_kernel(LeafArgs a) {
     __shared__ float4 tile[kTileUnits + 2 * kPadPairs + 16];   // + what the pipelined pair loop reads ahead of its last trip
     __shared__ uint32_t op_end[kMaxOps], op_base[kMaxOps];
     static_assert(kUnitsPerLane == 2 || kUnitsPerLane == 4, "the kernel names two or four staging registers");
-        const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const LeafBlock* __restrict__ bp = a.blocks + blockIdx.x;
     const uint32_t op_lo = bp->op_lo, op_n = bp->op_n;
