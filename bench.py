@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# multi-process GPU work on this pool's hosts needs dmabuf IPC (RCCL / cross-process device memory fail with
+# hipIpcGetMemHandle: invalid argument otherwise); the launcher's environment normally carries it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # host threads for the CPU baseline: the GPU box's CPU share for one GPU is 16 hardware threads
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
