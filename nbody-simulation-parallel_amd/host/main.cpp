@@ -354,6 +354,8 @@ void usage(const char* argv0) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+    // device memory shared between the ranks of --gpus G (RCCL) needs dmabuf IPC on this pool's hosts; kept if already set
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     Options opt;
     for (int i = 1; i < argc; ++i) {
         const std::string arg = argv[i];
