@@ -146,6 +146,14 @@ struct PairTerm {
     }
 };
 
+// Does any lane of the wave hold a pair (of the four of a trip) below the law's threshold?  The smallest of the four r^2 by two
+// v_min3_f32, one compare, one vote.
+template <int LAW, int D>
+__device__ __forceinline__ bool any_special(const PairTerm<D>& q0, const PairTerm<D>& q1) {
+    const float m = __builtin_fminf(__builtin_fminf(q0.r2.x, q0.r2.y), __builtin_fminf(q1.r2.x, q1.r2.y));
+    return __builtin_amdgcn_ballot_w64(m < law_special_below<LAW>()) != 0ull;
+}
+
 // The sums of one lane: fp32 per-tile level, fp64 second level.
 template <int D>
 struct Sums {
@@ -200,19 +208,21 @@ __device__ __forceinline__ void consume(const float4* __restrict__ s, const unsi
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i) { trip(a0, a1, a2, a3); s += 4; }
-        } else
-        for (unsigned i = n; i != 0u; --i, s += 4) {
-            const PairTerm<D> q0(s[0], s[1], ix2, iy2, iz2, bias), q1(s[2], s[3], ix2, iy2, iz2, bias);
-            f2 w0, w1;
-            if (GUARD && __builtin_expect((q0.template special<LAW>() | q1.template special<LAW>()) != 0ull, 0)) {   // wave-uniform, rare
-                w0 = q0.template guarded<LAW>();
-                w1 = q1.template guarded<LAW>();
-            } else {
-                w0 = q0.plain();
-                w1 = q1.plain();
+        } else {
+            // the guarded form keeps one register set (with two, the rare branch's live values push the kernel past 96 VGPRs)
+            for (unsigned i = n; i != 0u; --i, s += 4) {
+                const PairTerm<D> q0(s[0], s[1], ix2, iy2, iz2, bias), q1(s[2], s[3], ix2, iy2, iz2, bias);
+                f2 w0, w1;
+                if (__builtin_expect(any_special<LAW>(q0, q1), 0)) {   // wave-uniform, rare
+                    w0 = q0.template guarded<LAW>();
+                    w1 = q1.template guarded<LAW>();
+                } else {
+                    w0 = q0.plain();
+                    w1 = q1.plain();
+                }
+                S.add(q0, w0);
+                S.add(q1, w1);
             }
-            S.add(q0, w0);
-            S.add(q1, w1);
         }
         S.pending += 4u * n;
         done += n;

@@ -1,6 +1,8 @@
 """Near-field (leaf-pair) direct sums at FMM-like sizes: N bodies in a uniform grid of leaves (2^(3*level) cells), every
 leaf against its 27-cell neighbourhood, through nbx_leaf_pair_forces; prints the kernel's own time per law.
-    python tools/time_leaf_pairs.py [N] [level]"""
+    python tools/time_leaf_pairs.py [N] [level] [box]
+box (default: the reference generator's 1e7) rescales the positions: in a box below 2^14 = 16,384 every target lies inside the
+close set (csrc/nbx_internal.h) and every wave takes the kernel's guarded pair loop."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +11,8 @@ import nbody_amd as nbx
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 b = nbx.uniform_bodies(n, 3, 5)
+if len(sys.argv) > 3:
+    b[:, :3] *= float(sys.argv[3]) / 1.0e7
 leaves = nbx.leaves.uniform_grid_leaves(b, 3, level)
 lo, _, so, ss = leaves
 sizes = np.diff(lo).astype(np.int64)
