@@ -102,3 +102,41 @@ def test_bench_line_for_two_ranks_carries_parity(tmp_path):
     assert ab["default_fp32"]["max_backward"] <= 1e-5
     assert ab["mixed_mode"]["n_over_1e-5"] == 0 and ab["mixed_mode"]["max_rel"] <= 1e-5
     assert r["cpu_baseline"]["value"] > 0 and len(r["per_rank"]) == 2
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # bench.py's call
+assert dist.get_backend() == "nccl"
+compute, comm = torch.cuda.Stream(), torch.cuda.Stream()
+pos_all = torch.full((1, 3, 4096), float("nan"), device="cuda")                         # [n_shards][dim][pad], poisoned
+with torch.cuda.stream(compute):
+    pos_all[0].copy_(torch.arange(3 * 4096, device="cuda", dtype=torch.float32).view(3, 4096))
+comm.wait_stream(compute)                                                               # HipShardBackend.start_exchange
+with torch.cuda.stream(comm):
+    work = dist.all_gather_into_tensor(pos_all.view(-1), pos_all[0].view(-1), async_op=True)   # in place: src = own chunk
+with torch.cuda.stream(comm):                                                           # finish_exchange
+    work.wait()
+compute.wait_stream(comm)
+torch.cuda.synchronize()
+assert torch.equal(pos_all.view(-1).cpu(), torch.arange(3 * 4096, dtype=torch.float32))
+flag = torch.ones(1, device="cuda")
+dist.all_reduce(flag)                                                                   # the self-check's device collective
+assert float(flag) == 1.0
+dist.barrier()
+dist.destroy_process_group()
+print("rccl one rank ok")
+"""
+
+
+def test_rccl_call_pattern_with_one_rank():
+    """What one GPU can show of the RCCL branch before a multi-GPU node exists: torch's nccl backend initialises with bench.py's
+    arguments, and the exchange's call pattern -- wait on the compute stream, in-place all_gather_into_tensor of the own chunk with
+    async_op on the comm stream, wait, hand back to the compute stream -- runs and leaves the buffer intact.  One rank moves no
+    data between devices: the wire stays unexercised."""
+    import subprocess
+    p = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, str(_free_port())], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl one rank ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
