@@ -126,6 +126,12 @@ assert torch.equal(pos_all.view(-1).cpu(), torch.arange(3 * 4096, dtype=torch.fl
 flag = torch.ones(1, device="cuda")
 dist.all_reduce(flag)                                                                   # the self-check's device collective
 assert float(flag) == 1.0
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")                             # bench.py: max of the ranks' elapsed time
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.25
+gathered = [None]
+dist.all_gather_object(gathered, {"rank": 0, "ms": [1.0, 2.0]})                         # bench.py: per-rank pass times, parity rows
+assert gathered[0]["ms"] == [1.0, 2.0]
 dist.barrier()
 dist.destroy_process_group()
 print("rccl one rank ok")
