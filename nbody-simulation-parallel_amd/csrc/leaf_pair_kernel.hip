@@ -40,11 +40,11 @@ using namespace nbx;
 
 namespace {
 
-constexpr int kWaves = 2;                      // wave64 per workgroup: each owns one piece of the leaf's targets, both stage the tiles
-constexpr int kThreads = 64 * kWaves;
+constexpr int kMaxWaves = 2;                   // wave64 per workgroup: each owns one piece of the leaf's targets, all stage the tiles
 constexpr int kUnitsPerLane = 4;               // 16-byte units (= bodies) a lane stages per tile (the kernel names that many registers)
-constexpr int kTileUnits = kThreads * kUnitsPerLane;   // 512 bodies = 256 source pairs = 8 KB of LDS
+// a tile is 64 x WAVES x kUnitsPerLane bodies: 512 (256 source pairs, 8 KB of LDS) with two waves per workgroup
 constexpr int kPadPairs = 16;                  // massless pairs behind the tile's last one: the lane groups' last trips reach up to 2 P - 1 past it
+constexpr int kSmallLeaf = 20;                 // mean bodies per leaf up to which a workgroup is one wave (and one leaf piece)
 constexpr int kMaxOps = 64;                    // copy ops held in LDS at a time (longer lists go in chunks)
 constexpr int kMaxLanesPerTarget = 8;          // a piece of few targets gives each up to this many lanes (they split the sources)
 constexpr unsigned kFlushTerms = 248;          // fp32 terms per lane between flushes into the fp64 sums (+ 2 for a closing single pair)
@@ -158,7 +158,8 @@ __device__ __forceinline__ bool any_special(const PairTerm<D>& q0, const PairTer
 template <int D>
 struct Sums {
     f2 ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};
-    double* o;              // this lane's fp64 sums, kept in LDS (they are touched once per ~250 terms; 6 VGPRs less): o[0], o[kThreads], o[2 kThreads]
+    double* o;              // this lane's fp64 sums, kept in LDS (they are touched once per ~250 terms; 6 VGPRs less): o[0], o[stride], o[2 stride]
+    unsigned stride;        // lanes of the workgroup
     unsigned pending = 0;   // terms in the fp32 sums since the last flush (wave-uniform)
     __device__ __forceinline__ void add(const PairTerm<D>& q, const f2 w) {
         ax = __builtin_elementwise_fma(w, q.dx, ax);
@@ -167,8 +168,8 @@ struct Sums {
     }
     __device__ __forceinline__ void flush() {
         o[0] += (double)ax.x + (double)ax.y;
-        o[kThreads] += (double)ay.x + (double)ay.y;
-        if (D == 3) o[2 * kThreads] += (double)az.x + (double)az.y;
+        o[stride] += (double)ay.x + (double)ay.y;
+        if (D == 3) o[2u * stride] += (double)az.x + (double)az.y;
         ax = ay = az = f2{0.f, 0.f};
         pending = 0;
     }
@@ -243,8 +244,10 @@ __device__ __forceinline__ void consume(const float4* __restrict__ s, const unsi
 //    multiples of 32 B, which no two of <= 8 groups share a bank on.  Pairs past the tile's end are the pad pairs.
 //  * A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips i == j by
 //    index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
-template <int D, int LAW>
-__global__ __launch_bounds__(kThreads) void leaf_pair_kernel(LeafArgs a) {
+template <int D, int LAW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
+    constexpr int kThreads = 64 * WAVES;
+    constexpr int kTileUnits = kThreads * kUnitsPerLane;
     __shared__ float4 tile[kTileUnits + 2 * kPadPairs + 16];   // + what the pipelined pair loop reads ahead of its last trip
     __shared__ uint32_t op_end[kMaxOps], op_base[kMaxOps];
     static_assert(kUnitsPerLane == 2 || kUnitsPerLane == 4, "the kernel names two or four staging registers");
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void leaf_pair_kernel(LeafArgs a) {
     __shared__ double osum[3][kThreads];
     osum[0][tid] = 0.0; osum[1][tid] = 0.0; osum[2][tid] = 0.0;   // only this lane touches them until the closing barrier
     S.o = &osum[0][tid];
+    S.stride = (unsigned)kThreads;
     // a pad pair: unit {x,x,y,y} = far, unit {z,z,m,m} = {far (0 in 2D), 0}; selected by component (an indexed pair of constants ends up in scratch)
     const bool odd_unit = (tid & 1u) != 0u;
     const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
@@ -386,11 +390,13 @@ __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restr
 }
 
 typedef void (*LeafKernel)(LeafArgs);
-LeafKernel pick(int dim, int law) {
-    static const LeafKernel table[2][3] = {
-        {leaf_pair_kernel<2, NBX_LAW_BRUTE>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P>},
-        {leaf_pair_kernel<3, NBX_LAW_BRUTE>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P>}};
-    return table[dim - 2][law];
+LeafKernel pick(int dim, int law, int waves) {
+    static const LeafKernel table[2][2][3] = {
+        {{leaf_pair_kernel<2, NBX_LAW_BRUTE, 1>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, 1>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, 1>},
+         {leaf_pair_kernel<3, NBX_LAW_BRUTE, 1>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 1>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, 1>}},
+        {{leaf_pair_kernel<2, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, 2>},
+         {leaf_pair_kernel<3, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, 2>}}};
+    return table[waves - 1][dim - 2][law];
 }
 
 // How a run of c targets (<= 128) is cut into the two pieces of a workgroup: the cut that keeps the most lanes busy
@@ -520,18 +526,24 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         if (ops.size() > 0xfffffff0ull) return fail(NBX_ERR_INVALID, "source lists too long");
     }
     op_off[n_leaves] = (uint32_t)ops.size();
-    // workgroups: 128 targets of a leaf at most, cut into the two waves' pieces
+    // workgroups.  Leaves of the size the reference's FMM keeps (tens of bodies, methods.h:26): two waves, 128 targets of a leaf at
+    // most, cut into the two waves' pieces.  Small leaves (the BVH's 16 bodies and below): one wave per workgroup and no cut -- a
+    // leaf of 16 fills a wave at 4 lanes per target, and a workgroup barrier costs more than two waves sharing ~100 staged bodies save.
+    size_t nonempty = 0;
+    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
+    const int waves = (nonempty && slots / nonempty <= (size_t)kSmallLeaf) ? 1 : kMaxWaves;
+    const uint32_t per_group = 64u * (uint32_t)waves;
     static const PieceCut cuts = best_cuts();
     std::vector<LeafBlock> blocks;
     blocks.reserve(n_leaves);
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (!c) continue;
-        const uint32_t groups = (c + 127u) / 128u;
+        const uint32_t groups = (c + per_group - 1u) / per_group;
         uint32_t f = unit_off[l];
         for (uint32_t gi = 0; gi < groups; ++gi) {
-            const uint32_t share = c / groups + (gi < c % groups ? 1u : 0u);   // <= 128
-            const uint32_t c1 = cuts.c1[share];
+            const uint32_t share = c / groups + (gi < c % groups ? 1u : 0u);   // <= 64 x waves
+            const uint32_t c1 = waves == 2 ? cuts.c1[share] : share;
             LeafBlock b;
             b.op_lo = op_off[l];
             b.op_n = op_off[l + 1] - op_off[l];
@@ -608,7 +620,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     const int timed_from = reps / 2;
     for (int r = 0; r < reps; ++r) {
         if (r == timed_from) NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-        hipLaunchKernelGGL(pick(dim, law), dim3((unsigned)blocks.size()), dim3(kThreads), 0, d.stream, a);
+        hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
         NBX_HIP_TRY(hipGetLastError());
     }
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));

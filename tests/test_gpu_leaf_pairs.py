@@ -125,15 +125,16 @@ def test_ragged_structure_and_close_pairs(nbx, oracle):
 
 
 @pytest.mark.parametrize("dim", (3, 2))
-@pytest.mark.parametrize("big", (False, True))
+@pytest.mark.parametrize("big", (False, True, "small"))
 def test_every_block_shape_and_long_lists(nbx, oracle, dim, big):
-    """Target leaves of every size from 1 to 70 or 1 to 258 in steps of 3 (big: up to three workgroups per leaf), so that every
-    lanes-per-target count, every cut of a leaf into the two waves' pieces and every partly filled last tile occurs; source
-    lists of 1 to 300 entries in random order, with repeats and empty leaves in them (more copy runs than the kernel holds in
-    LDS at a time: chunked; streams of several tiles), odd and even leaf sizes (padded source pairs); all three laws."""
-    sizes = list(range(1, 71)) if not big else list(range(1, 260, 3))
+    """Target leaves of every size from 1 to 70, or 1 to 258 in steps of 3 (big: up to three workgroups per leaf), or 1 to 30 with a
+    mean of 12 (small: the library launches one wave per workgroup, the leaf uncut), so that every lanes-per-target count, every
+    cut of a leaf into the two waves' pieces and every partly filled last tile occurs; source lists of 1 to 300 entries in random
+    order, with repeats and empty leaves in them (more copy runs than the kernel holds in LDS at a time: chunked; streams of
+    several tiles), odd and even leaf sizes (padded source pairs); all three laws."""
+    sizes = list(range(1, 71)) if big is False else list(range(1, 260, 3)) if big is True else list(range(1, 25)) * 3 + [30, 27]
     sizes += [0, 0]                                                  # two empty leaves, also as sources
-    rng = np.random.default_rng(90 + dim + 2 * big)
+    rng = np.random.default_rng(90 + dim + 2 * (big is True) + 5 * (big == "small"))
     order = rng.permutation(len(sizes))
     sizes = [sizes[i] for i in order]
     n = sum(sizes) + 17                                              # 17 bodies in no leaf
