@@ -18,7 +18,9 @@
 //  * one workgroup = two wave64 = ONE leaf: the waves share the staged tiles (512 bodies) and each owns one PIECE of
 //    the leaf's targets.  A piece of c targets runs floor(64 / c) lanes per target (at most 8), which split the
 //    tile's pairs between them; the host cuts the leaf where the two pieces together waste the fewest lanes
-//    (43 targets: 11 x 5 lanes + 32 x 2 lanes = 96 % of the lanes busy; one wave64 with one lane each: 67 %);
+//    (43 targets: 11 x 5 lanes + 32 x 2 lanes = 96 % of the lanes busy; one wave64 with one lane each: 67 %).  Small leaves
+//    (a mean of <= 20 bodies) get one wave per workgroup and no cut;
+//  * the workgroups are launched longest first, so that the launch drains in a fraction of a mean workgroup's time;
 //  * the law's special cases sit below r^2 = 1e-9.  A target whose fp32 coordinates are all >= 2^14 in magnitude
 //    cannot own such a pair other than with an identical position (the brute-force kernel's argument,
 //    nbx_internal.h: distinct fp32 numbers that large differ by >= 2^-10), so a block of such targets runs the pair
