@@ -45,7 +45,7 @@ $(CSRC)/nbx_node.o: $(CSRC)/nbx_node.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.
 $(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c $< -o $@
 
-$(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
+$(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/leaf_plan.h $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS) $(CSRC)/libnbody_hip.map

@@ -13,7 +13,7 @@
 //    ends in a massless body far away), so a source leaf is a run of whole pairs that is copied into LDS as it lies
 //    and read back with ds_read_b128 straight into the aligned register pairs of v_pk_*_f32;
 //  * a leaf's source list becomes a few COPY OPS on the host: consecutive list entries whose leaves are neighbours
-//    in leaf order are merged (the 27 cells of a grid neighbourhood are 9 runs), with the running length of the
+//    in leaf order are merged (the 27 cells of a grid neighbourhood are 9 to 11 runs), with the running length of the
 //    stream they form -- no list walk, no leaf-offset lookup and no prefix sum on the device;
 //  * one workgroup = two wave64 = ONE leaf: the waves share the staged tiles (512 bodies) and each owns one PIECE of
 //    the leaf's targets.  A piece of c targets runs floor(64 / c) lanes per target (at most 8), which split the
@@ -32,6 +32,7 @@
 // is tens of thousands of short workgroups; HBM traffic is 16 B per (workgroup, source body), served mostly from L2.
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
+#include "leaf_plan.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -39,16 +40,14 @@
 #include <vector>
 
 using namespace nbx;
+using namespace nbx_leaf;
 
 namespace {
 
-constexpr int kMaxWaves = 2;                   // wave64 per workgroup: each owns one piece of the leaf's targets, all stage the tiles
 constexpr int kUnitsPerLane = 4;               // 16-byte units (= bodies) a lane stages per tile (the kernel names that many registers)
 // a tile is 64 x WAVES x kUnitsPerLane bodies: 512 (256 source pairs, 8 KB of LDS) with two waves per workgroup
 constexpr int kPadPairs = 16;                  // massless pairs behind the tile's last one: the lane groups' last trips reach up to 2 P - 1 past it
-constexpr int kSmallLeaf = 20;                 // mean bodies per leaf up to which a workgroup is one wave (and one leaf piece)
 constexpr int kMaxOps = 64;                    // copy ops held in LDS at a time (longer lists go in chunks)
-constexpr int kMaxLanesPerTarget = 8;          // a piece of few targets gives each up to this many lanes (they split the sources)
 constexpr unsigned kFlushTerms = 248;          // fp32 terms per lane between flushes into the fp64 sums (+ 2 for a closing single pair)
 
 // smallest fp32 thresholds that are >= the reference's fp64 ones, so (r2 < T_f32) == ((double)r2 < T) for fp32 r2
@@ -60,21 +59,6 @@ static_assert((double)kTreeSkipF >= 1e-9 && (double)kSmoothF >= 1e-10 && (double
               "fp32 thresholds must sit on the right side of the fp64 ones");
 constexpr float kFar = 1.0e18f;                 // pad bodies: massless, r^2 ~ 1e36 is finite in fp32 and the weight underflows to 0
 static_assert(kTreeSkipF < 9.0e-7f, "a target outside the close set (nbx_internal.h) has no non-zero r^2 below 9.5e-7: no law's special case can apply to it");
-
-struct Piece {
-    uint32_t first;    // first target (padded slot)
-    uint32_t count;    // <= 64; 0: this wave only helps staging
-};
-struct LeafBlock {     // one workgroup; read with scalar loads
-    uint32_t op_lo, op_n;   // the leaf's copy ops
-    uint32_t pad_[2];       // [0]: host-side sort key
-    Piece piece[2];
-};
-static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
-struct CopyOp {
-    uint32_t end;      // length of the leaf's source stream up to and including this run, in 16-byte units
-    uint32_t base;     // unit of the run's first body minus the stream position it lands on (mod 2^32): source = base + position
-};
 
 struct LeafArgs {
     const float4* __restrict__ xp;     // [pslots] units: pair p = units 2p {xa,xb,ya,yb} and 2p+1 {za,zb,ma,mb}
@@ -401,31 +385,6 @@ LeafKernel pick(int dim, int law, int waves) {
     return table[waves - 1][dim - 2][law];
 }
 
-// How a run of c targets (<= 128) is cut into the two pieces of a workgroup: the cut that keeps the most lanes busy
-// (a piece of c runs min(64 / c, 8) lanes per target and takes 1 / that of the source pairs' trips), the more even one among equals.
-struct PieceCut { uint8_t c1[129]; };
-PieceCut best_cuts() {
-    PieceCut r;
-    auto trips = [](int c) -> double {
-        if (c == 0) return 0.0;
-        int lanes = 64 / c;
-        if (lanes > kMaxLanesPerTarget) lanes = kMaxLanesPerTarget;
-        return 1.0 / lanes;
-    };
-    r.c1[0] = 0;
-    for (int c = 1; c <= 128; ++c) {
-        double best = 1e30, best_max = 1e30;
-        int arg = c <= 64 ? c : 64;
-        for (int a = (c > 64 ? c - 64 : 0); a <= c && a <= 64; ++a) {
-            const double ta = trips(a), tb = trips(c - a);
-            const double sum = ta + tb, mx = ta > tb ? ta : tb;
-            if (sum < best - 1e-12 || (sum < best + 1e-12 && mx < best_max - 1e-12)) { best = sum; best_max = mx; arg = a; }
-        }
-        r.c1[c] = (uint8_t)arg;
-    }
-    return r;
-}
-
 struct DeviceBuffers {   // frees whatever was allocated when the call leaves, on every path
     std::vector<void*> ptrs;
     hipStream_t stream = nullptr;
@@ -483,100 +442,14 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
-    // ---- the layout the kernel follows (comment at the top of the file) ----
-    // padded slots: a leaf of odd size gets one more slot, so that every leaf is a run of whole source pairs
-    std::vector<uint32_t> unit_off(n_leaves + 1);
-    {
-        uint64_t u = 0;
-        for (size_t l = 0; l < n_leaves; ++l) {
-            unit_off[l] = (uint32_t)u;
-            u += (uint64_t)((leaf_offsets[l + 1] - leaf_offsets[l] + 1u) & ~1u);
-        }
-        if (u > 0xfffffff0ull) return fail(NBX_ERR_INVALID, "too many bodies / leaves");
-        unit_off[n_leaves] = (uint32_t)u;
-    }
-    const size_t pslots = unit_off[n_leaves];
-    std::vector<uint32_t> pslot_body(pslots);              // body of each padded slot, 0xffffffff for a leaf's pad
-    for (size_t l = 0; l < n_leaves; ++l) {
-        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
-        if (c) memcpy(&pslot_body[unit_off[l]], leaf_bodies + leaf_offsets[l], (size_t)c * sizeof(uint32_t));
-        if (c & 1u) pslot_body[unit_off[l] + c] = 0xffffffffu;
-    }
-    // copy ops: the source list of each leaf as runs of consecutive units (neighbours in leaf order merged), empty leaves dropped
-    std::vector<CopyOp> ops;
-    std::vector<uint32_t> op_off(n_leaves + 1);
-    ops.reserve(n_list / 2 + 16);
-    for (size_t l = 0; l < n_leaves; ++l) {
-        op_off[l] = (uint32_t)ops.size();
-        uint64_t stream = 0;        // units so far
-        uint32_t run_first = 0, run_len = 0;
-        auto close_run = [&]() {
-            if (!run_len) return;
-            stream += run_len;
-            ops.push_back(CopyOp{(uint32_t)stream, run_first - (uint32_t)(stream - run_len)});
-            run_len = 0;
-        };
-        for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e) {
-            const uint32_t s = list_sources[e];
-            const uint32_t first = unit_off[s], len = unit_off[s + 1] - unit_off[s];
-            if (!len) continue;
-            if (run_len && first == run_first + run_len) run_len += len;
-            else { close_run(); run_first = first; run_len = len; }
-            if (stream + run_len > 0xfffff000ull) return fail(NBX_ERR_INVALID, "a leaf's source list names more than 2^32 bodies");
-        }
-        close_run();
-        if (ops.size() > 0xfffffff0ull) return fail(NBX_ERR_INVALID, "source lists too long");
-    }
-    op_off[n_leaves] = (uint32_t)ops.size();
-    // workgroups.  Leaves of the size the reference's FMM keeps (tens of bodies, methods.h:26): two waves, 128 targets of a leaf at
-    // most, cut into the two waves' pieces.  Small leaves (the BVH's 16 bodies and below): one wave per workgroup and no cut -- a
-    // leaf of 16 fills a wave at 4 lanes per target, and a workgroup barrier costs more than two waves sharing ~100 staged bodies save.
-    size_t nonempty = 0;
-    for (size_t l = 0; l < n_leaves; ++l) nonempty += leaf_offsets[l + 1] > leaf_offsets[l];
-    const int waves = (nonempty && slots / nonempty <= (size_t)kSmallLeaf) ? 1 : kMaxWaves;
-    const uint32_t per_group = 64u * (uint32_t)waves;
-    static const PieceCut cuts = best_cuts();
-    std::vector<LeafBlock> blocks;
-    blocks.reserve(n_leaves);
-    for (size_t l = 0; l < n_leaves; ++l) {
-        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
-        if (!c) continue;
-        const uint32_t groups = (c + per_group - 1u) / per_group;
-        uint32_t f = unit_off[l];
-        for (uint32_t gi = 0; gi < groups; ++gi) {
-            const uint32_t share = c / groups + (gi < c % groups ? 1u : 0u);   // <= 64 x waves
-            const uint32_t c1 = waves == 2 ? cuts.c1[share] : share;
-            LeafBlock b;
-            b.op_lo = op_off[l];
-            b.op_n = op_off[l + 1] - op_off[l];
-            b.pad_[0] = b.pad_[1] = 0;
-            b.piece[0] = Piece{f, c1};
-            b.piece[1] = Piece{f + c1, share - c1};
-            {   // how long the workgroup will run: the slower wave's trips over the leaf's stream (sort key below)
-                auto lanes = [](uint32_t c) -> uint32_t { const uint32_t p = c ? 64u / c : (uint32_t)kMaxLanesPerTarget; return p > (uint32_t)kMaxLanesPerTarget ? (uint32_t)kMaxLanesPerTarget : p; };
-                const uint32_t stream_units = b.op_n ? ops[b.op_lo + b.op_n - 1].end : 0u;
-                const uint32_t slower = lanes(c1) < lanes(share - c1) ? lanes(c1) : lanes(share - c1);
-                b.pad_[0] = stream_units / slower;
-            }
-            blocks.push_back(b);
-            f += share;
-        }
-    }
-    // Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
-    // short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).
-    // A counting sort over 1024 duration classes, leaf order kept within a class (neighbours share their sources in L2).
-    if (blocks.size() > 1) {
-        uint32_t longest = 1;
-        for (const LeafBlock& b : blocks) if (b.pad_[0] > longest) longest = b.pad_[0];
-        constexpr uint32_t kClasses = 1024;
-        auto cls = [&](const LeafBlock& b) -> uint32_t { return (kClasses - 1u) - (uint32_t)((uint64_t)b.pad_[0] * (kClasses - 1u) / longest); };
-        std::vector<uint32_t> start(kClasses + 1, 0u);
-        for (const LeafBlock& b : blocks) ++start[cls(b) + 1u];
-        for (uint32_t k = 0; k < kClasses; ++k) start[k + 1] += start[k];
-        std::vector<LeafBlock> sorted(blocks.size());
-        for (const LeafBlock& b : blocks) sorted[start[cls(b)]++] = b;
-        blocks.swap(sorted);
-    }
+    // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
+    LeafPlan plan;
+    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan)) return fail(NBX_ERR_INVALID, why);
+    const size_t pslots = plan.pslots();
+    const std::vector<uint32_t>& pslot_body = plan.pslot_body;
+    const std::vector<CopyOp>& ops = plan.ops;
+    const std::vector<LeafBlock>& blocks = plan.blocks;
+    const int waves = plan.waves;
 
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;

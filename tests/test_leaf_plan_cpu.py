@@ -1,0 +1,129 @@
+"""CPU: the host side of the leaf-pair path (csrc/leaf_plan.h) -- padded source pairs, copy runs, the cut of every leaf into its
+workgroup's pieces, the launch order -- compiled with g++ and checked for its invariants on ragged structures, without a GPU.
+What the pair kernel computes from the plan is the GPU tests' business (tests/test_gpu_leaf_pairs.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAD = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def planner(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("leaf_plan") / "leaf_plan_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], check=True)
+
+    def run(workdir, lo, lb, so, ss):
+        for name, a in (("leaf_offsets", lo), ("leaf_bodies", lb), ("list_offsets", so), ("list_sources", ss)):
+            np.asarray(a, dtype=np.uint32).tofile(os.path.join(workdir, name + ".u32"))
+        p = subprocess.run([exe, workdir], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out = {k: np.fromfile(os.path.join(workdir, k + ".u32"), dtype=np.uint32) for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks")}
+        out["waves"] = int(p.stdout.split()[1])
+        out["ops"] = out["ops"].reshape(-1, 2)          # (end, base)
+        out["blocks"] = out["blocks"].reshape(-1, 8)    # op_lo, op_n, key, -, first0, count0, first1, count1
+        return out
+    return run
+
+
+def _structure(seed, sizes, list_len):
+    rng = np.random.default_rng(seed)
+    sizes = np.asarray(sizes)
+    lo = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(lo[-1]) + 11
+    lb = rng.permutation(n)[:lo[-1]]
+    lists = []
+    for t in range(sizes.size):
+        k = list_len(t)
+        l = rng.integers(0, sizes.size, k)
+        if t % 2 == 0 and k >= 3:                       # runs of consecutive leaves: these must be merged
+            start = int(rng.integers(0, max(1, sizes.size - 3)))
+            l[:3] = [start, start + 1, start + 2]
+        lists.append(l)
+    so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    ss = np.concatenate(lists) if lists else np.zeros(0, dtype=np.int64)
+    return lo, lb, so, ss
+
+
+def _check(plan, lo, lb, so, ss):
+    sizes = np.diff(lo)
+    unit_off, pslot_body, ops, op_off, blocks = (plan[k] for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks"))
+    # padded slots: every leaf a whole number of pairs, bodies in leaf order, one pad at the end of an odd leaf
+    psz = np.diff(unit_off.astype(np.int64))
+    assert unit_off[0] == 0 and (psz == (sizes + 1) // 2 * 2).all()
+    for l in range(sizes.size):
+        seg = pslot_body[unit_off[l]:unit_off[l + 1]]
+        assert (seg[:sizes[l]] == lb[lo[l]:lo[l + 1]]).all() and (seg[sizes[l]:] == PAD).all()
+    # copy runs: expanded, a leaf's runs are its list's leaves (empty ones dropped) unit by unit, in list order; `end` is the running length
+    n_merged = 0
+    for l in range(sizes.size):
+        want = [np.arange(unit_off[s], unit_off[s + 1]) for s in ss[so[l]:so[l + 1]] if psz[s]]
+        want = np.concatenate(want) if want else np.zeros(0, dtype=np.int64)
+        runs = ops[op_off[l]:op_off[l + 1]].astype(np.int64)
+        begin, got = 0, []
+        for end, base in runs:
+            assert end > begin
+            got.append((np.arange(begin, end) + base) % (1 << 32))
+            begin = end
+        got = np.concatenate(got) if got else np.zeros(0, dtype=np.int64)
+        assert got.size == want.size and (got == want).all(), l
+        n_entries = sum(1 for s in ss[so[l]:so[l + 1]] if psz[s])
+        n_merged += n_entries - runs.shape[0]
+    # workgroups: every body a target of exactly one piece, pieces inside one leaf and at most 64 targets, the leaf's runs attached
+    hit = np.zeros(unit_off[-1], dtype=np.int64)
+    leaf_of_unit = np.repeat(np.arange(sizes.size), psz)
+    waves = plan["waves"]
+    nonempty = sizes[sizes > 0]
+    assert waves == (1 if nonempty.size and nonempty.sum() // nonempty.size <= 20 else 2)
+    for op_lo, op_n, key, _, f0, c0, f1, c1 in blocks.astype(np.int64):
+        assert c0 <= 64 and c1 <= 64 and c0 + c1 >= 1 and (waves == 2 or c1 == 0)
+        l = leaf_of_unit[f0 if c0 else f1]
+        assert op_lo == op_off[l] and op_n == op_off[l + 1] - op_off[l]
+        for f, c in ((f0, c0), (f1, c1)):
+            if c:
+                assert (leaf_of_unit[f:f + c] == l).all() and (pslot_body[f:f + c] != PAD).all()
+                hit[f:f + c] += 1
+        if c0 and c1:
+            assert f1 == f0 + c0
+    assert (hit == (pslot_body != PAD)).all()
+    # launch order: longest first (1024 duration classes)
+    key = blocks[:, 2].astype(np.int64)
+    if key.size > 1:
+        cls = key * 1023 // max(int(key.max()), 1)
+        assert (np.diff(cls) <= 0).all()
+    return n_merged
+
+
+def test_plan_of_ragged_structures(planner, tmp_path):
+    cases = [
+        (1, list(range(1, 71)) + [0, 0], lambda t: [1, 2, 3, 27, 64, 65, 129, 300][t % 8]),          # every piece cut, long lists
+        (2, list(range(1, 260, 3)) + [0], lambda t: [5, 27, 0][t % 3]),                                # several workgroups per leaf, empty lists
+        (3, list(range(1, 25)) * 3 + [30, 27], lambda t: 9),                                           # small leaves: one wave per workgroup
+        (4, [0, 0, 0], lambda t: 2),                                                                   # nothing but empty leaves
+        (5, [64, 128, 129, 1, 65], lambda t: 5),
+    ]
+    merged = 0
+    for seed, sizes, list_len in cases:
+        d = tmp_path / f"case{seed}"
+        d.mkdir()
+        lo, lb, so, ss = _structure(seed, sizes, list_len)
+        merged += _check(planner(str(d), lo, lb, so, ss), lo, lb, so, ss)
+    assert merged > 50, "consecutive leaves on a list must be merged into one run"
+
+
+def test_grid_neighbourhoods_become_a_few_runs(planner, tmp_path):
+    """A 3D grid's 27-cell list is 9 runs of 3 consecutive cells; the builder names the leaf itself first, which splits one of them:
+    at most 11 runs (list order is kept), fewer at the faces -- the list walk the kernel no longer does."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import nbody_amd as nbx
+    b = nbx.uniform_bodies(20000, 3, 7)
+    lo, lb, so, ss = nbx.leaves.uniform_grid_leaves(b, 3, 3)
+    plan = planner(str(tmp_path), lo, lb, so, ss)
+    _check(plan, lo, lb, so, ss)
+    runs = np.diff(plan["op_off"].astype(np.int64))
+    assert runs.max() <= 11 and runs.min() >= 4 and np.diff(so).max() == 27, (runs.min(), runs.max())
+    assert plan["waves"] == 2
