@@ -443,7 +443,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     }
 
     // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
-    LeafPlan plan;
+    static thread_local LeafPlan plan;   // a tree code calls once per step: the arrays keep their capacity (and their pages) between calls
     if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan)) return fail(NBX_ERR_INVALID, why);
     const size_t pslots = plan.pslots();
     const std::vector<uint32_t>& pslot_body = plan.pslot_body;

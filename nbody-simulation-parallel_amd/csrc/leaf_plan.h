@@ -72,7 +72,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
     // padded slots: a leaf of odd size gets one more slot, so that every leaf is a run of whole source pairs
     std::vector<uint32_t>& unit_off = plan.unit_off;
-    unit_off.assign(n_leaves + 1, 0u);
+    unit_off.resize(n_leaves + 1);              // every entry is written below
     {
         uint64_t u = 0;
         for (size_t l = 0; l < n_leaves; ++l) {
@@ -84,7 +84,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     }
     const size_t pslots = unit_off[n_leaves];
     std::vector<uint32_t>& pslot_body = plan.pslot_body;
-    pslot_body.assign(pslots, 0u);              // body of each padded slot, 0xffffffff for a leaf's pad
+    pslot_body.resize(pslots);                  // every slot is written below: bodies by the copy, an odd leaf's pad explicitly              // body of each padded slot, 0xffffffff for a leaf's pad
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (c) memcpy(&pslot_body[unit_off[l]], leaf_bodies + leaf_offsets[l], (size_t)c * sizeof(uint32_t));
@@ -94,7 +94,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     std::vector<CopyOp>& ops = plan.ops;
     ops.clear();
     std::vector<uint32_t>& op_off = plan.op_off;
-    op_off.assign(n_leaves + 1, 0u);
+    op_off.resize(n_leaves + 1);
     ops.reserve(n_list / 2 + 16);
     for (size_t l = 0; l < n_leaves; ++l) {
         op_off[l] = (uint32_t)ops.size();
