@@ -1,5 +1,6 @@
 """CPU: the host side of the leaf-pair path (csrc/leaf_plan.h) -- padded source pairs, copy runs, the cut of every leaf into its
-workgroup's pieces, the launch order -- compiled with g++ and checked for its invariants on ragged structures, without a GPU.
+workgroup's pieces, the launch order -- compiled with g++ under AddressSanitizer and UBSan (sanitizers run on the CPU build only) and checked for its invariants on ragged
+structures, without a GPU.
 What the pair kernel computes from the plan is the GPU tests' business (tests/test_gpu_leaf_pairs.py)."""
 import os
 import subprocess
@@ -14,7 +15,7 @@ PAD = 0xFFFFFFFF
 @pytest.fixture(scope="module")
 def planner(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("leaf_plan") / "leaf_plan_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], check=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], check=True)
 
     def run(workdir, lo, lb, so, ss):
         for name, a in (("leaf_offsets", lo), ("leaf_bodies", lb), ("list_offsets", so), ("list_sources", ss)):
