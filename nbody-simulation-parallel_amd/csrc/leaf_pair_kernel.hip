@@ -23,10 +23,11 @@
 //  * the workgroups are launched longest first, so that the launch drains in a fraction of a mean workgroup's time;
 //  * the law's special cases sit below r^2 = 1e-9.  A target whose fp32 coordinates are all >= 2^14 in magnitude
 //    cannot own such a pair other than with an identical position (the brute-force kernel's argument,
-//    nbx_internal.h: distinct fp32 numbers that large differ by >= 2^-10), so a block of such targets runs the pair
+//    nbx_internal.h: distinct fp32 numbers that large differ by >= 2^-10), so a wave of such targets runs the pair
 //    loop with no compare at all: r^2 biased by 2^-47, an identical position contributes m 2^94 x 0 = 0 as every law
-//    asks.  The host decides per block; the other blocks take the guarded loop (one v_cmp per pair, a wave vote,
-//    and the law's exact weights for the wave that saw a pair below the threshold).
+//    asks.  Each wave decides for itself from its lanes' own coordinates (and the call's largest mass); the other waves
+//    take the guarded loop (the smallest r^2 of a trip's four pairs, one compare, a wave vote, and the law's exact
+//    weights for the wave that saw a pair below the threshold).
 // fp32 sums over at most 256 terms per lane, flushed into fp64 accumulators.  No atomics, a fixed summation order,
 // every output written once.  Leaves are small (the reference caps them at 100 bodies, methods.h:26), so the launch
 // is tens of thousands of short workgroups; HBM traffic is 16 B per (workgroup, source body), served mostly from L2.
