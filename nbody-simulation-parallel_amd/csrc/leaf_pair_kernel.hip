@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace nbx;
@@ -386,14 +387,58 @@ LeafKernel pick(int dim, int law, int waves) {
     return table[waves - 1][dim - 2][law];
 }
 
-struct DeviceBuffers {   // frees whatever was allocated when the call leaves, on every path
-    std::vector<void*> ptrs;
+// The call's device arrays are one allocation, and a tree code calls once per step with arrays of the same size: the allocation
+// of a finished call is parked (one per device, up to kArenaParkMax bytes) and taken by the next call it is large enough for --
+// hipMalloc + hipFree of ~100 MB cost 0.5 ms of a 4.4-ms call.  nbx_release_cached() frees the parked ones.
+constexpr size_t kArenaParkMax = (size_t)2 << 30;
+struct ParkedArena { int device; char* p; size_t bytes; };
+std::mutex g_arena_mu;
+std::vector<ParkedArena> g_arenas;
+
+hipError_t take_arena(int device, size_t bytes, char** out, size_t* got) {
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mu);
+        for (size_t i = 0; i < g_arenas.size(); ++i)
+            if (g_arenas[i].device == device && g_arenas[i].bytes >= bytes) {
+                *out = g_arenas[i].p;
+                *got = g_arenas[i].bytes;
+                g_arenas.erase(g_arenas.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    *got = bytes;
+    return hipMalloc((void**)out, bytes);
+}
+
+void park_arena(int device, char* p, size_t bytes) {   // nothing on the device uses p any more
+    char* evicted = nullptr;
+    if (bytes <= kArenaParkMax) {
+        std::lock_guard<std::mutex> lock(g_arena_mu);
+        for (size_t i = 0; i < g_arenas.size(); ++i)
+            if (g_arenas[i].device == device) {         // one per device: keep the larger
+                if (g_arenas[i].bytes >= bytes) { evicted = p; p = nullptr; }
+                else { evicted = g_arenas[i].p; g_arenas[i] = ParkedArena{device, p, bytes}; p = nullptr; }
+                break;
+            }
+        if (p) { g_arenas.push_back(ParkedArena{device, p, bytes}); p = nullptr; }
+    } else {
+        evicted = p;
+    }
+    if (evicted) (void)hipFree(evicted);
+}
+
+struct DeviceBuffers {   // gives back whatever the call took when it leaves, on every path
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
     hipStream_t stream = nullptr;
     int device = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DeviceBuffers() {
         const bool idle = stream && hipStreamSynchronize(stream) == hipSuccess;
-        for (void* p : ptrs) (void)hipFree(p);
+        if (arena) {
+            if (idle) park_arena(device, arena, arena_bytes);
+            else (void)hipFree(arena);
+        }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (idle) nbx::park_stream(device, stream);   // back to the pool (nbx_api.hip): a stream costs more than this call's kernels
@@ -402,6 +447,22 @@ struct DeviceBuffers {   // frees whatever was allocated when the call leaves, o
 };
 
 }  // namespace
+
+namespace nbx {
+void release_parked_leaf_arenas() {
+    std::vector<ParkedArena> parked;
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mu);
+        parked.swap(g_arenas);
+    }
+    int before = 0;
+    const bool have = hipGetDevice(&before) == hipSuccess;
+    for (ParkedArena& a : parked)
+        if (hipSetDevice(a.device) == hipSuccess) (void)hipFree(a.p);
+    if (have) (void)hipSetDevice(before);
+    (void)hipGetLastError();
+}
+}  // namespace nbx
 
 extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, const uint32_t* leaf_offsets,
                                     const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
@@ -463,9 +524,8 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
                              pslots * sizeof(uint32_t), ops.size() * sizeof(CopyOp), blocks.size() * sizeof(LeafBlock), sizeof(uint32_t)};
     size_t offs[8], total_bytes = 0;
     for (int i = 0; i < 8; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
-    char* arena = nullptr;
-    NBX_HIP_TRY(hipMalloc((void**)&arena, total_bytes));
-    d.ptrs.push_back(arena);
+    NBX_HIP_TRY(take_arena(device, total_bytes, &d.arena, &d.arena_bytes));
+    char* const arena = d.arena;
     double* raw = reinterpret_cast<double*>(arena + offs[0]);
     float4* xp = reinterpret_cast<float4*>(arena + offs[1]);
     double* acc = reinterpret_cast<double*>(arena + offs[2]);

@@ -459,6 +459,7 @@ int nbx_device_count(int* count) {
 
 int nbx_release_cached(void) {
     release_parked_communicators();
+    release_parked_leaf_arenas();
     release_parked_streams();
     return NBX_OK;
 }

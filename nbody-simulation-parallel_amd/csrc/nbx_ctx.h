@@ -107,6 +107,7 @@ void release_parked_streams();
 int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3]);
 int upload_finish(nbx_ctx* c, const unsigned long long facts[3]);
 void release_parked_communicators();   // nbx_node.hip
+void release_parked_leaf_arenas();     // leaf_pair_kernel.hip
 }  // namespace nbx
 
 #define NBX_HIP_TRY(expr)                                                           \

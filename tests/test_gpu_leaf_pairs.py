@@ -226,3 +226,21 @@ def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
     sizes = np.diff(lo).astype(np.int64)
     pairs = int(sum(sizes[t] * sizes[ss[so[t]:so[t + 1]]].sum() for t in range(sizes.size)))
     print(f"\nleaf-pair kernel: N={n}, {sizes.size} leaves (max {sizes.max()}), {pairs:.3e} pair terms in {ms:.2f} ms = {pairs / ms * 1e3:.3e} pairs/s")
+
+
+def test_calls_reuse_the_parked_device_allocation(nbx, oracle):
+    """A finished call parks its device allocation for the next one on that device (a tree code calls once per step); results must
+    not depend on what the allocation held before: a large call, then smaller ones of another shape, a release in between."""
+    lib = nbx.load_library()
+    big = oracle.round_inputs_to_f32(oracle.generate(140, 30000, 3))
+    big_leaves = nbx.leaves.uniform_grid_leaves(big, 3, 3)
+    f_big = nbx.leaf_pair_forces_hip(big, *big_leaves, law=nbx.LAW_FMM_P2P, G=oracle.G)
+    small = oracle.round_inputs_to_f32(oracle.generate(141, 3000, 2))
+    small_leaves = nbx.leaves.uniform_grid_leaves(small, 2, 3)
+    f1 = nbx.leaf_pair_forces_hip(small, *small_leaves, law=nbx.LAW_TREE_LEAF, G=oracle.G)      # inside the big call's allocation
+    assert lib.nbx_release_cached() == 0
+    f2 = nbx.leaf_pair_forces_hip(small, *small_leaves, law=nbx.LAW_TREE_LEAF, G=oracle.G)      # a fresh one
+    assert np.array_equal(f1, f2)
+    _check(nbx, oracle, small, small_leaves, nbx.LAW_TREE_LEAF, "small call inside a parked allocation")
+    assert np.array_equal(f_big, nbx.leaf_pair_forces_hip(big, *big_leaves, law=nbx.LAW_FMM_P2P, G=oracle.G))   # grows again
+    assert lib.nbx_release_cached() == 0
