@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace nbx;
@@ -391,6 +392,8 @@ LeafKernel pick(int dim, int law, int waves) {
 // of a finished call is parked (one per device, up to kArenaParkMax bytes) and taken by the next call it is large enough for --
 // hipMalloc + hipFree of ~100 MB cost 0.5 ms of a 4.4-ms call.  nbx_release_cached() frees the parked ones.
 constexpr size_t kArenaParkMax = (size_t)2 << 30;
+constexpr size_t kArenasPerDevice = 2;
+constexpr size_t kHelperCopyBytes = (size_t)4 << 20;   // staged bodies from this size on are copied by a helper thread while the launch is laid out
 struct ParkedArena { int device; char* p; size_t bytes; };
 std::mutex g_arena_mu;
 std::vector<ParkedArena> g_arenas;
@@ -398,13 +401,15 @@ std::vector<ParkedArena> g_arenas;
 hipError_t take_arena(int device, size_t bytes, char** out, size_t* got) {
     {
         std::lock_guard<std::mutex> lock(g_arena_mu);
+        size_t best = g_arenas.size();
         for (size_t i = 0; i < g_arenas.size(); ++i)
-            if (g_arenas[i].device == device && g_arenas[i].bytes >= bytes) {
-                *out = g_arenas[i].p;
-                *got = g_arenas[i].bytes;
-                g_arenas.erase(g_arenas.begin() + (long)i);
-                return hipSuccess;
-            }
+            if (g_arenas[i].device == device && g_arenas[i].bytes >= bytes && (best == g_arenas.size() || g_arenas[i].bytes < g_arenas[best].bytes)) best = i;
+        if (best != g_arenas.size()) {
+            *out = g_arenas[best].p;
+            *got = g_arenas[best].bytes;
+            g_arenas.erase(g_arenas.begin() + (long)best);
+            return hipSuccess;
+        }
     }
     *got = bytes;
     return hipMalloc((void**)out, bytes);
@@ -414,13 +419,17 @@ void park_arena(int device, char* p, size_t bytes) {   // nothing on the device 
     char* evicted = nullptr;
     if (bytes <= kArenaParkMax) {
         std::lock_guard<std::mutex> lock(g_arena_mu);
+        g_arenas.push_back(ParkedArena{device, p, bytes});
+        size_t mine = 0, smallest = g_arenas.size();
         for (size_t i = 0; i < g_arenas.size(); ++i)
-            if (g_arenas[i].device == device) {         // one per device: keep the larger
-                if (g_arenas[i].bytes >= bytes) { evicted = p; p = nullptr; }
-                else { evicted = g_arenas[i].p; g_arenas[i] = ParkedArena{device, p, bytes}; p = nullptr; }
-                break;
+            if (g_arenas[i].device == device) {
+                ++mine;
+                if (smallest == g_arenas.size() || g_arenas[i].bytes < g_arenas[smallest].bytes) smallest = i;
             }
-        if (p) { g_arenas.push_back(ParkedArena{device, p, bytes}); p = nullptr; }
+        if (mine > kArenasPerDevice) {                      // a call takes two (bodies; everything else): keep the two largest
+            evicted = g_arenas[smallest].p;
+            g_arenas.erase(g_arenas.begin() + (long)smallest);
+        }
     } else {
         evicted = p;
     }
@@ -428,8 +437,10 @@ void park_arena(int device, char* p, size_t bytes) {   // nothing on the device 
 }
 
 struct DeviceBuffers {   // gives back whatever the call took when it leaves, on every path
-    char* arena = nullptr;
+    char* arena = nullptr;          // everything but the staged bodies
     size_t arena_bytes = 0;
+    char* body_arena = nullptr;     // the staged Body<D> array
+    size_t body_bytes = 0;
     hipStream_t stream = nullptr;
     int device = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -438,6 +449,10 @@ struct DeviceBuffers {   // gives back whatever the call took when it leaves, on
         if (arena) {
             if (idle) park_arena(device, arena, arena_bytes);
             else (void)hipFree(arena);
+        }
+        if (body_arena) {
+            if (idle) park_arena(device, body_arena, body_bytes);
+            else (void)hipFree(body_arena);
         }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -504,6 +519,27 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
+    NBX_HIP_TRY(hipSetDevice(device));
+    DeviceBuffers d;
+    d.device = device;
+    NBX_HIP_TRY(nbx::take_stream(device, &d.stream));
+    NBX_HIP_TRY(hipEventCreate(&d.ev0));
+    NBX_HIP_TRY(hipEventCreate(&d.ev1));
+    // The bodies go to the device on a helper thread (58 MB at N = 2^20; the copy from pageable memory blocks its caller for 1 ms)
+    // while this thread lays out the launch.
+    NBX_HIP_TRY(take_arena(device, n * stride_bytes + 256, &d.body_arena, &d.body_bytes));
+    double* const raw = reinterpret_cast<double*>(d.body_arena);
+    hipError_t copy_rc = hipSuccess;
+    std::thread copier;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{copier};   // before d goes, on every path
+    if (n * stride_bytes >= kHelperCopyBytes)
+        copier = std::thread([&]() {
+            copy_rc = hipSetDevice(device);
+            if (copy_rc == hipSuccess) copy_rc = hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream);
+        });
+    else   // a thread costs more than a small copy takes
+        NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
+
     // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
     static thread_local LeafPlan plan;   // a tree code calls once per step: the arrays keep their capacity (and their pages) between calls
     if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan)) return fail(NBX_ERR_INVALID, why);
@@ -513,28 +549,22 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     const std::vector<LeafBlock>& blocks = plan.blocks;
     const int waves = plan.waves;
 
-    NBX_HIP_TRY(hipSetDevice(device));
-    DeviceBuffers d;
-    d.device = device;
-    NBX_HIP_TRY(nbx::take_stream(device, &d.stream));
-    NBX_HIP_TRY(hipEventCreate(&d.ev0));
-    NBX_HIP_TRY(hipEventCreate(&d.ev1));
-    // one allocation for the call's device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
-    const size_t sizes[8] = {n * stride_bytes, pslots * sizeof(float4), (size_t)dim * pslots * sizeof(double), n * (size_t)dim * sizeof(double),
+    // one allocation for the call's other device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
+    const size_t sizes[7] = {pslots * sizeof(float4), (size_t)dim * pslots * sizeof(double), n * (size_t)dim * sizeof(double),
                              pslots * sizeof(uint32_t), ops.size() * sizeof(CopyOp), blocks.size() * sizeof(LeafBlock), sizeof(uint32_t)};
-    size_t offs[8], total_bytes = 0;
-    for (int i = 0; i < 8; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
+    size_t offs[7], total_bytes = 0;
+    for (int i = 0; i < 7; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
     NBX_HIP_TRY(take_arena(device, total_bytes, &d.arena, &d.arena_bytes));
     char* const arena = d.arena;
-    double* raw = reinterpret_cast<double*>(arena + offs[0]);
-    float4* xp = reinterpret_cast<float4*>(arena + offs[1]);
-    double* acc = reinterpret_cast<double*>(arena + offs[2]);
-    double* dforces = reinterpret_cast<double*>(arena + offs[3]);
-    uint32_t* d_pb = reinterpret_cast<uint32_t*>(arena + offs[4]);
-    CopyOp* d_ops = reinterpret_cast<CopyOp*>(arena + offs[5]);
-    LeafBlock* d_blocks = reinterpret_cast<LeafBlock*>(arena + offs[6]);
-    uint32_t* d_max_mass = reinterpret_cast<uint32_t*>(arena + offs[7]);
-    NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
+    float4* xp = reinterpret_cast<float4*>(arena + offs[0]);
+    double* acc = reinterpret_cast<double*>(arena + offs[1]);
+    double* dforces = reinterpret_cast<double*>(arena + offs[2]);
+    uint32_t* d_pb = reinterpret_cast<uint32_t*>(arena + offs[3]);
+    CopyOp* d_ops = reinterpret_cast<CopyOp*>(arena + offs[4]);
+    LeafBlock* d_blocks = reinterpret_cast<LeafBlock*>(arena + offs[5]);
+    uint32_t* d_max_mass = reinterpret_cast<uint32_t*>(arena + offs[6]);
+    if (copier.joinable()) copier.join();
+    NBX_HIP_TRY(copy_rc);
     NBX_HIP_TRY(hipMemcpyAsync(d_pb, pslot_body.data(), pslots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     if (!ops.empty()) NBX_HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(CopyOp), hipMemcpyHostToDevice, d.stream));
     NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(LeafBlock), hipMemcpyHostToDevice, d.stream));
