@@ -532,12 +532,16 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     hipError_t copy_rc = hipSuccess;
     std::thread copier;
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{copier};   // before d goes, on every path
-    if (n * stride_bytes >= kHelperCopyBytes)
-        copier = std::thread([&]() {
-            copy_rc = hipSetDevice(device);
-            if (copy_rc == hipSuccess) copy_rc = hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream);
-        });
-    else   // a thread costs more than a small copy takes
+    if (n * stride_bytes >= kHelperCopyBytes) {
+        try {
+            copier = std::thread([&]() {
+                copy_rc = hipSetDevice(device);
+                if (copy_rc == hipSuccess) copy_rc = hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream);
+            });
+        } catch (...) {   // no thread to be had: copy here
+        }
+    }
+    if (!copier.joinable())   // small input (a thread costs more than the copy takes), or no thread
         NBX_HIP_TRY(hipMemcpyAsync(raw, bodies, n * stride_bytes, hipMemcpyHostToDevice, d.stream));
 
     // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
