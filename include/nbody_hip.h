@@ -18,6 +18,11 @@
  *    boundary.  Returned forces are F_i = -(G m_i) * sum_j m_j (p_j - p_i)/r^4 with pairs of
  *    r^2 < 1e-10 skipped -- the reference law exactly as written (methods.cpp:21-37), including its
  *    sign and its extra power of r; G*m_i is applied in fp64.
+ *  - PRECISION DEFAULT: the reference's arithmetic is fp64 (vector.h:9-12); every entry point below runs the
+ *    MIXED MODE by default -- fp32 pair terms for every target, then an fp64 re-evaluation of the targets whose
+ *    fp32 sum cannot be trusted to 1e-5 relative (nbx_ctx_set_refine) -- so that every body's force is within
+ *    1e-5 relative of brute_force_seq_n_body on the same (fp32-representable) inputs.  nbx_set_default_refine
+ *    changes the tolerance for contexts made afterwards; 0 = plain fp32 (a few bodies per 100,000 then miss 1e-5).
  *  - There is NO CPU fallback: without a usable HIP device every compute call fails with
  *    NBX_ERR_NO_DEVICE / NBX_ERR_HIP.
  */
@@ -35,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NBX_ABI_VERSION 3   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only) */
+#define NBX_ABI_VERSION 4   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only); 4: mixed mode ON by default (nbx_set_default_refine), nbx_brute_force_forces_ex, nbx_node_refine_stats, the leaf plan (nbx_leaf_plan_*); nbx_leaf_pair_forces no longer reads NBX_LEAF_TIMING_REPS */
 
 /* status codes */
 enum {
@@ -70,6 +75,14 @@ int nbx_warmup(int device);
  * a communicator set for 8 GPUs far more -- against a force evaluation of 0.07 ms at N = 1,000).  This gives them
  * back; a harness calls it before it exits.  Safe to call at any time; live contexts and nodes are not touched. */
 int nbx_release_cached(void);
+/* Process-wide precision default taken by every context, node and one-shot call created AFTER this call (thread-safe):
+ * rel_tolerance = 0: plain fp32; otherwise the mixed mode of nbx_ctx_set_refine with this tolerance and sigma factor
+ * (0 = the library's calibrated factor).  The library starts with (1e-5, 0): the north star's tolerance for every body.
+ * Same argument ranges as nbx_ctx_set_refine (NBX_ERR_INVALID otherwise). */
+int nbx_set_default_refine(double rel_tolerance, double sigma_factor);
+int nbx_get_default_refine(double* rel_tolerance, double* sigma_factor);
+/* The calibrated sigma factor the mixed mode uses for `dim` when the caller passes 0 (tests pin it). */
+double nbx_refine_sigma_default(int dim);
 
 /* ---- one-shot entry points (host memory in, host memory out) --------------------------------- */
 
@@ -81,6 +94,22 @@ int nbx_release_cached(void);
  * the wall time of the whole call is what the reference's safely_execute (utils.h:87-104) times. */
 int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
                            double G, int device, double* forces_out, float* kernel_ms);
+/* The same call with the precision spelled out and a report of what ran.  rel_tolerance < 0: the process default
+ * (nbx_set_default_refine); 0: plain fp32; > 0: mixed mode with this tolerance.  info (optional) receives:
+ *   kernel_ms        the force kernel's device time (hipEvent pair around it);  refine_ms  that of the mixed mode's select /
+ *                    fp64 / fold kernels that followed it (0 in plain fp32)
+ *   refine_tolerance the tolerance that was in force (0: plain fp32, or the mixed mode does not apply to the kernel that ran)
+ *   refine_selected  targets the selection rule listed;  refine_refined  targets re-evaluated in fp64 (always equal: the
+ *                    fp64 pass has room for every target of the shard -- a long list costs time, never accuracy)
+ *   variant          kernel variant that ran (nbx_variant_name);  close_set_mode  NBX_CLOSE_* of the evaluation */
+typedef struct nbx_eval_info {
+    float kernel_ms, refine_ms;
+    double refine_tolerance;
+    unsigned refine_selected, refine_refined;
+    int variant, close_set_mode;
+} nbx_eval_info;
+int nbx_brute_force_forces_ex(const void* bodies, size_t n, int dim, size_t body_stride_bytes, double G, int device,
+                              double rel_tolerance, double* forces_out, nbx_eval_info* info);
 
 /* Replaces the loop  { f = brute_force_*_n_body(bodies); update_body_velocities(bodies, f, dt);
  * update_body_positions(bodies, dt); }  repeated nsteps times (methods.h:85-91; methods.cpp:425-450;
@@ -214,7 +243,9 @@ int nbx_ctx_set_tuning(nbx_ctx* ctx, int source_splits, int variant);
  *                              pair, or an exact variant selected)
  *   NBX_CLOSE_NONE             softened law: nothing to guard
  * Decided at upload and re-evaluated during long runs from an asynchronous read-back of the device counters every 16
- * steps (never a wait) -- also inside one long nbx_ctx_step call, whose graph replays go out in blocks of 16 steps.  candidates_seen / bad_seen: the most recent counts the host has seen (0 before the first). */
+ * steps (never a wait) -- also inside one long nbx_ctx_step call, whose graph replays go out in blocks of 16 steps (the look takes effect
+ * within the call only while the device keeps up with the host: at large N the host has queued every block before the first
+ * copy lands, and the next call acts on it; a change of mode inside the call drains the stream before the step is re-captured).  candidates_seen / bad_seen: the most recent counts the host has seen (0 before the first). */
 enum { NBX_CLOSE_CANDIDATE_PAIRS = 0, NBX_CLOSE_SORTED_CELLS = 1, NBX_CLOSE_GUARDED_KERNEL = 2, NBX_CLOSE_NONE = 3 };
 int nbx_ctx_close_set_mode(nbx_ctx* ctx, int* mode, unsigned* candidates_seen, unsigned* bad_seen);
 
@@ -244,12 +275,13 @@ int nbx_ctx_set_law(nbx_ctx* ctx, int law);
  *    Q_i = sum over the 256-source tiles of |tile partial sum|^2 (accumulated by the fast kernel at no measurable cost);
  *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
  *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
- *    calibrated default (48 in 3D, 64 in 2D).  rel_tolerance = 0 switches the mode off (default).  Ignored with a softening length, the
- *    Newtonian law, or a non-fast variant.  At most 1/16 of a shard's targets (at least 16,384) are re-evaluated per force
- *    evaluation; nbx_ctx_refine_stats reports how many the rule selected and how many were re-evaluated. */
+ *    calibrated default (nbx_refine_sigma_default).  rel_tolerance = 0 switches the mode off; a new context starts with the
+ *    process default (nbx_set_default_refine: 1e-5 unless changed).  Ignored with a softening length, the
+ *    Newtonian law, or a non-fast variant.  EVERY selected target is re-evaluated: the fp64 pass has room for the whole
+ *    shard (its source slices shrink as the list grows, on the device) -- nbx_ctx_refine_stats reports the count. */
 int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);
 /* After a mixed-mode force evaluation: selected = targets the rule listed, refined = those re-evaluated in fp64
- * (= min(selected, capacity)).  Either pointer may be NULL.  Synchronises the stream. */
+ * (the same number: there is no capacity to overflow).  Either pointer may be NULL.  Synchronises the stream. */
 int nbx_ctx_refine_stats(nbx_ctx* ctx, unsigned* selected, unsigned* refined);
 /* The per-target statistic the last force evaluation wrote beside the accelerations, double[shard_len]:
  *   mixed mode:                  Q_i = sum over the source tiles of |tile partial sum|^2 (what the selection rule thresholds);
@@ -266,6 +298,9 @@ int nbx_default_variant(void);
 /* Mean duration in ms of the force-kernel launches since the last call (hipEvent pairs recorded on
  * the context's stream around each launch), and how many launches that covers.  Synchronises. */
 int nbx_ctx_kernel_time(nbx_ctx* ctx, float* mean_ms, int* launches);
+/* Device time in ms (total, not mean) of the mixed mode's select / fp64 re-evaluation / fold kernels that followed the force-kernel
+ * launches covered by the LAST nbx_ctx_kernel_time call (graph-replayed steps carry theirs inside the whole-step time). */
+int nbx_ctx_refine_time(nbx_ctx* ctx, float* total_ms);
 
 /* ---- single-process multi-GPU node ---------------------------------------------------------------
  * The reference is single-process, single-device; this is new.  One context per rank
@@ -296,6 +331,8 @@ int nbx_node_set_tuning(nbx_node* node, int source_splits, int variant);
 int nbx_node_set_softening(nbx_node* node, double epsilon);   /* nbx_ctx_set_softening on every rank */
 int nbx_node_set_law(nbx_node* node, int law);                /* nbx_ctx_set_law on every rank */
 int nbx_node_set_refine(nbx_node* node, double rel_tolerance, double sigma_factor);   /* nbx_ctx_set_refine on every rank */
+/* nbx_ctx_refine_stats summed over the ranks (after nbx_node_compute_forces / a step); NBX_ERR_STATE when no rank ran the mixed mode. */
+int nbx_node_refine_stats(nbx_node* node, unsigned* selected, unsigned* refined);
 /* Forces on all n_total bodies (Vector<dim>[n_total]); same contract as nbx_brute_force_forces. */
 int nbx_node_compute_forces(nbx_node* node, double G, double* forces_out);
 /* nsteps x { exchange || local forces; remote forces; kick+drift } on every rank.  Asynchronous. */

@@ -34,7 +34,11 @@ ABI = [
     ("nbx_device_count", _i, [_pi]),
     ("nbx_warmup", _i, [_i]),
     ("nbx_release_cached", _i, []),
+    ("nbx_set_default_refine", _i, [_d, _d]),
+    ("nbx_get_default_refine", _i, [_pd, _pd]),
+    ("nbx_refine_sigma_default", _d, [_i]),
     ("nbx_brute_force_forces", _i, [_vp, _sz, _i, _sz, _d, _i, _vp, _pf]),
+    ("nbx_brute_force_forces_ex", _i, [_vp, _sz, _i, _sz, _d, _i, _d, _vp, _vp]),
     ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
     ("nbx_leaf_pair_forces", _i, [_vp, _sz, _i, _sz, _vp, _vp, _sz, _vp, _vp, _i, _d, _i, _vp, _pf]),
     ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),
@@ -66,6 +70,7 @@ ABI = [
     ("nbx_variant_name", _c.c_char_p, [_i]),
     ("nbx_default_variant", _i, []),
     ("nbx_ctx_kernel_time", _i, [_vp, _pf, _pi]),
+    ("nbx_ctx_refine_time", _i, [_vp, _pf]),
     ("nbx_node_create", _i, [_c.POINTER(_vp), _i, _pi, _i, _sz, _i]),
     ("nbx_node_destroy", _i, [_vp]),
     ("nbx_node_exchange_mode", _i, [_vp, _pi]),
@@ -75,6 +80,7 @@ ABI = [
     ("nbx_node_set_softening", _i, [_vp, _d]),
     ("nbx_node_set_law", _i, [_vp, _i]),
     ("nbx_node_set_refine", _i, [_vp, _d, _d]),
+    ("nbx_node_refine_stats", _i, [_vp, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
     ("nbx_node_compute_forces", _i, [_vp, _d, _vp]),
     ("nbx_node_step", _i, [_vp, _d, _d, _i]),
     ("nbx_node_step_kdk", _i, [_vp, _d, _d, _i]),
@@ -151,20 +157,53 @@ def variants():
     return [lib.nbx_variant_name(i).decode() for i in range(lib.nbx_num_variants())]
 
 
+class EvalInfo(ctypes.Structure):
+    """nbx_eval_info of include/nbody_hip.h: what the one-shot evaluation ran."""
+    _fields_ = [("kernel_ms", _c.c_float), ("refine_ms", _c.c_float), ("refine_tolerance", _d), ("refine_selected", _c.c_uint), ("refine_refined", _c.c_uint),
+                ("variant", _i), ("close_set_mode", _i)]
+
+
+def set_default_refine(rel_tolerance: float, sigma_factor: float = 0.0):
+    """Process-wide precision default of contexts / nodes / one-shot calls made afterwards (nbx_set_default_refine):
+    0 = plain fp32, otherwise the mixed mode's relative tolerance.  The library starts with 1e-5."""
+    lib = load_library()
+    _check(lib, lib.nbx_set_default_refine(float(rel_tolerance), float(sigma_factor)), "nbx_set_default_refine")
+
+
+def get_default_refine() -> Tuple[float, float]:
+    lib = load_library()
+    a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _check(lib, lib.nbx_get_default_refine(ctypes.byref(a), ctypes.byref(b)), "nbx_get_default_refine")
+    return a.value, b.value
+
+
+def refine_sigma_default(dim: int) -> float:
+    return float(load_library().nbx_refine_sigma_default(int(dim)))
+
+
 def brute_force_hip_n_body(bodies: np.ndarray, G: float = REFERENCE_G, device: int = 0,
-                           return_kernel_ms: bool = False):
+                           return_kernel_ms: bool = False, rel_tolerance: Optional[float] = None, return_info: bool = False):
     """forces = brute_force_hip_n_body(bodies): drop-in for brute_force_seq_n_body<D> /
     brute_force_omp_n_body_{1,2}<D> (nbody-sim-new/methods.h:29-37).  bodies: float64 [n, 2D+1];
-    returns float64 [n, D] forces (Vector<D> per body)."""
+    returns float64 [n, D] forces (Vector<D> per body).  rel_tolerance: None = the process default (mixed mode, 1e-5),
+    0 = plain fp32, > 0 = mixed mode with this tolerance (nbx_brute_force_forces_ex); return_info adds the EvalInfo."""
     lib = load_library()
     b, dim = _as_bodies(bodies)
     n = b.shape[0]
     out = np.empty((n, dim), dtype=np.float64)
-    ms = ctypes.c_float(0.0)
-    rc = lib.nbx_brute_force_forces(b.ctypes.data, n, dim, b.shape[1] * 8, G, device, out.ctypes.data,
-                                    ctypes.byref(ms))
-    _check(lib, rc, "nbx_brute_force_forces")
-    return (out, ms.value) if return_kernel_ms else out
+    if rel_tolerance is None and not return_info:
+        ms = ctypes.c_float(0.0)
+        rc = lib.nbx_brute_force_forces(b.ctypes.data, n, dim, b.shape[1] * 8, G, device, out.ctypes.data,
+                                        ctypes.byref(ms))
+        _check(lib, rc, "nbx_brute_force_forces")
+        return (out, ms.value) if return_kernel_ms else out
+    info = EvalInfo()
+    rc = lib.nbx_brute_force_forces_ex(b.ctypes.data, n, dim, b.shape[1] * 8, G, device,
+                                       -1.0 if rel_tolerance is None else float(rel_tolerance), out.ctypes.data, ctypes.byref(info))
+    _check(lib, rc, "nbx_brute_force_forces_ex")
+    if return_info:
+        return out, info
+    return (out, info.kernel_ms) if return_kernel_ms else out
 
 
 def leapfrog_hip_n_body(bodies: np.ndarray, dt: float, nsteps: int, G: float = REFERENCE_G, device: int = 0):
@@ -346,6 +385,13 @@ class Context:
         return ms.value, cnt.value
 
 
+    def refine_time(self) -> float:
+        """Total ms of the mixed mode's kernels behind the evaluations the last kernel_time() call covered."""
+        ms = ctypes.c_float(0.0)
+        self._ck(self.lib.nbx_ctx_refine_time(self.h, ctypes.byref(ms)), "nbx_ctx_refine_time")
+        return ms.value
+
+
 class Node:
     """Single-process multi-GPU node (nbx_node_* of include/nbody_hip.h): one rank per entry of `devices`
     (a device may repeat: virtual ranks on one GPU)."""
@@ -404,6 +450,12 @@ class Node:
 
     def set_refine(self, rel_tolerance: float, sigma_factor: float = 0.0):
         self._ck(self.lib.nbx_node_set_refine(self.h, float(rel_tolerance), float(sigma_factor)), "nbx_node_set_refine")
+
+    def refine_stats(self) -> Tuple[int, int]:
+        """(selected, refined) of the last mixed-mode evaluation, summed over the ranks."""
+        a, b = ctypes.c_uint(0), ctypes.c_uint(0)
+        self._ck(self.lib.nbx_node_refine_stats(self.h, ctypes.byref(a), ctypes.byref(b)), "nbx_node_refine_stats")
+        return a.value, b.value
 
     def forces(self, G: float = REFERENCE_G) -> np.ndarray:
         out = np.empty((self.n_total, self.dim), dtype=np.float64)

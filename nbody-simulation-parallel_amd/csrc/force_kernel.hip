@@ -319,6 +319,25 @@ __device__ __forceinline__ void store_hi_lo(const KArgs& a, float* __restrict__ 
     lo_plane[idx] = (float)(v - (double)hi);
 }
 
+// Layout of the mixed mode's fp64 pass, decided on the device from the length of the list the selection just wrote (the
+// host never learns it: the step stays one graph).  strict_acc holds [slices][D][stride] doubles, stride = the list's length
+// rounded up to whole blocks of 256; as many source slices (<= the launch's gridDim.y) as fit the buffer.  A short list --
+// the usual case, a fraction of a percent of the shard -- spreads one or two list blocks over up to 256 slices; a long
+// one has the list blocks to fill the chip and gets fewer slices; the whole shard still fits one slice.  Nothing overflows.
+struct StrictLayout { unsigned n, stride, slices, tiles_per_split; };
+template <int D>
+__device__ __forceinline__ StrictLayout strict_layout(const KArgs& a) {
+    StrictLayout s;
+    const unsigned listed = a.counters[3];
+    s.n = listed < a.strict_cap ? listed : a.strict_cap;   // the list cannot be longer than the shard; a guard, not a limit
+    s.stride = s.n ? (s.n + 255u) / 256u * 256u : 256u;
+    unsigned long long fit = a.strict_budget / ((unsigned long long)D * s.stride);
+    if (fit > (unsigned long long)a.strict_slices) fit = (unsigned long long)a.strict_slices;
+    s.slices = fit ? (unsigned)fit : 1u;
+    s.tiles_per_split = (a.total_tiles + s.slices - 1u) / s.slices;
+    return s;
+}
+
 // MAG = 1 (diagnostic build): also S_i = sum_j |a_ij|, the sum of the pair terms' magnitudes, into aux[slice][i] -- what the
 // relative error of a cancelling sum is measured against (tests: backward error of the fp32 path for EVERY body).
 template <int D, int TPL, int WAVES, int UNROLL, int NR, int LIST, int MAG = 0>
@@ -329,8 +348,12 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
     unsigned bx, by;
     if (LIST) { bx = blockIdx.x; by = blockIdx.y; } else xcd_tile(bx, by);
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
-    const unsigned n_list = LIST ? a.counters[3] : 0u;
-    const unsigned n_listed = n_list < a.strict_cap ? n_list : a.strict_cap;
+    unsigned n_listed = 0u, out_stride = 0u, tiles_per_split = a.tiles_per_split;
+    if (LIST) {
+        const StrictLayout sl = strict_layout<D>(a);
+        if (by >= sl.slices) return;   // workgroup-uniform, before any barrier
+        n_listed = sl.n; out_stride = sl.stride; tiles_per_split = sl.tiles_per_split;
+    }
     const unsigned nblk = LIST ? (n_listed + 256u * TPL - 1u) / (256u * TPL) : bx + 1u;
 
     for (unsigned tb = bx; tb < nblk; tb += LIST ? gridDim.x : nblk) {
@@ -347,9 +370,10 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
             ox[q] = oy[q] = oz[q] = 0.0;
             if (MAG) om[q] = 0.0;
         }
-        unsigned t = by * a.tiles_per_split;
-        unsigned t_end = t + a.tiles_per_split;
+        unsigned t = by * tiles_per_split;
+        unsigned t_end = t + tiles_per_split;
         if (t_end > a.total_tiles) t_end = a.total_tiles;
+        if (t > t_end) t = t_end;   // a slice beyond the last tile (the rounding of tiles_per_split) adds nothing
         TileWalk w;
         w.seek(t, a.tiles_per_chunk);
         float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -373,14 +397,14 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
             buf ^= 1;
         }
         if (LIST) {
-            double* __restrict__ o = a.strict_acc + (size_t)by * D * a.strict_cap;
+            double* __restrict__ o = a.strict_acc + (size_t)by * D * out_stride;
 #pragma unroll
             for (int q = 0; q < TPL; ++q) {
                 const unsigned slot = slot0 + q * 256u;
                 if (slot < n_listed) {
                     o[slot] = ox[q];
-                    o[(size_t)a.strict_cap + slot] = oy[q];
-                    if (D == 3) o[2 * (size_t)a.strict_cap + slot] = oz[q];
+                    o[(size_t)out_stride + slot] = oy[q];
+                    if (D == 3) o[2 * (size_t)out_stride + slot] = oz[q];
                 }
             }
             __syncthreads();   // the next list block reuses the tile buffers
@@ -694,19 +718,19 @@ __global__ __launch_bounds__(256) void refine_select_kernel(KArgs a) {
     const bool suspect = a.bad_flag[i] != 0u || !(Q * a.refine_c2 <= n2);   // a NaN anywhere lists the target
     if (suspect) {
         const unsigned slot = atomicAdd(&a.counters[3], 1u);
-        if (slot < a.strict_cap) a.strict_list[slot] = i;   // beyond the cap the fp32 result stands (counted, reported)
+        if (slot < a.strict_cap) a.strict_list[slot] = i;   // strict_cap = the shard's pad >= count: always true
     }
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void refine_fold_kernel(KArgs a) {
-    const unsigned n_list = a.counters[3];
-    const unsigned n = n_list < a.strict_cap ? n_list : a.strict_cap;
+    const StrictLayout sl = strict_layout<D>(a);
+    const unsigned n = sl.n;
     for (unsigned slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u) {
         const unsigned i = a.strict_list[slot];
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
-            for (int y = 0; y < a.strict_slices; ++y) v += a.strict_acc[((size_t)y * D + k) * a.strict_cap + slot];
+            for (unsigned y = 0; y < sl.slices; ++y) v += a.strict_acc[((size_t)y * D + k) * sl.stride + slot];
             const float hi = (float)v;
             a.acc[(size_t)k * a.pad + i] = hi;
             if (a.splits > 1) a.acc[((size_t)D + k) * a.pad + i] = (float)(v - (double)hi);

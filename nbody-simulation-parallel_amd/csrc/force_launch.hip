@@ -78,7 +78,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.accumulate = L.accumulate;
     a.splits = L.splits;
     a.qsum = L.qsum;
-    a.strict_list = nullptr; a.strict_acc = nullptr; a.strict_cap = 0; a.strict_slices = 0; a.refine_c2 = 0.0;
+    a.strict_list = nullptr; a.strict_acc = nullptr; a.strict_cap = 0; a.strict_slices = 0; a.strict_budget = 0; a.refine_c2 = 0.0;
     a.cand_list = L.cand_list;
     a.cand_pos = L.cand_pos;
     a.bad_list = L.bad_list;
@@ -169,6 +169,7 @@ hipError_t refine_args(int dim, const RefineLaunch& R, KArgs& a) {
     a.splits = L.splits;
     a.bad_flag = L.bad_flag; a.counters = L.counters; a.qsum = L.qsum;
     a.strict_list = R.strict_list; a.strict_acc = R.strict_acc; a.strict_cap = R.strict_cap; a.strict_slices = R.strict_slices;
+    a.strict_budget = R.strict_budget;
     a.refine_c2 = R.c2;
     return hipSuccess;
 }
@@ -178,9 +179,12 @@ hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
     KArgs a;
     hipError_t e = refine_args(dim, R, a);
     if (e != hipSuccess) return e;
-    if (!R.strict_list || !R.strict_acc || R.strict_cap == 0 || R.strict_slices < 1 || (unsigned)R.strict_slices > a.total_tiles)
+    // the list has room for every target of the shard, and the sums for the whole shard in one slice: whatever the selection
+    // lists is re-evaluated (the device picks slices x stride within the budget, force_kernel.hip strict_layout)
+    if (!R.strict_list || !R.strict_acc || R.strict_cap < R.base.pad || R.strict_slices < 1 || R.strict_slices > 256 ||
+        (unsigned)R.strict_slices > a.total_tiles || R.strict_budget < (unsigned long long)dim * R.base.pad)
         return hipErrorInvalidValue;
-    a.tiles_per_split = (a.total_tiles + (unsigned)R.strict_slices - 1) / (unsigned)R.strict_slices;
+    a.tiles_per_split = 0;   // the fp64 pass derives its own from the list's length
     if (a.count == 0) return hipSuccess;
     const int di = dim - 2;
     const dim3 block(256, 1, 1);
@@ -188,7 +192,9 @@ hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
     hipLaunchKernelGGL(table().ck.refine_select[di], dim3((a.count + 255u) / 256u, 1, 1), block, 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // listed targets x strict slices; a workgroup whose list block does not exist returns at once
-    const unsigned list_blocks = (R.strict_cap + 255u) / 256u;
+    // grid.x = list blocks taken in turn by a row of workgroups: a short list (the usual case) needs one or two, and rows of
+    // idle workgroups cost a scalar load each; 32 x 256 workgroups of one target per lane fill the chip for a long one
+    const unsigned list_blocks = (a.count + 255u) / 256u;
     hipLaunchKernelGGL(table().ck.strict_list[di], dim3(list_blocks < 32u ? list_blocks : 32u, (unsigned)R.strict_slices, 1), block, 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(table().ck.refine_fold[di], dim3(64, 1, 1), block, 0, stream, a);

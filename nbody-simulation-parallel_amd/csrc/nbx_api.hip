@@ -5,6 +5,7 @@
 #include "nbx_internal.h"
 #include "nbx_ctx.h"
 
+#include <atomic>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -103,7 +104,15 @@ constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from
 constexpr double kRefineSigmaDefault3D = 48.0;
 constexpr double kRefineSigmaDefault2D = 64.0;
 constexpr double kUnitRoundoffF32 = 0x1p-24;
-constexpr size_t kStrictAccBytesMax = (size_t)256 << 20;
+// Precision default of new contexts (nbx_set_default_refine): the north star's tolerance for every body
+std::atomic<double> g_default_refine_tol{1.0e-5};
+std::atomic<double> g_default_refine_sigma{0.0};
+
+bool refine_args_ok(double rel_tolerance, double sigma_factor, const char** why) {
+    if (!(rel_tolerance == 0.0 || (rel_tolerance >= 1.0e-7 && rel_tolerance <= 1.0e-2))) { *why = "refine tolerance must be 0 (off) or in [1e-7, 1e-2]"; return false; }
+    if (!(sigma_factor >= 0.0 && sigma_factor <= 1.0e6)) { *why = "sigma factor must be 0 (default) or in (0, 1e6]"; return false; }
+    return true;
+}
 
 }  // namespace
 
@@ -217,6 +226,23 @@ int slices_for(const nbx_ctx* c, int variant) {
     return s < 1 ? 1 : s;
 }
 
+// Mixed mode's fp64 pass: a list with room for EVERY target of the shard, and sums for up to 256 source slices of a list of
+// typical length (1/64 of the shard: the rule lists well under a percent of uniform or Plummer 3D bodies, a few percent in
+// 2D) -- at least the whole shard in one slice.  The device picks slices x stride within this budget from the list's actual
+// length (force_kernel.hip strict_layout): a long list costs time, never accuracy.
+void strict_sizes(nbx_ctx* c, size_t* list_bytes, size_t* acc_bytes) {
+    c->strict_cap = c->pad;
+    const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
+    c->strict_slices = tiles < 256u ? (int)tiles : 256;
+    size_t typical = ((size_t)c->pad / 64 + 255) / 256 * 256;
+    if (typical < 256) typical = 256;
+    size_t per_comp = typical * (size_t)c->strict_slices;
+    if (per_comp < c->pad) per_comp = c->pad;
+    c->strict_budget = (unsigned long long)c->dim * per_comp;
+    *list_bytes = (size_t)c->strict_cap * sizeof(unsigned);
+    *acc_bytes = (size_t)c->strict_budget * sizeof(double);
+}
+
 int ensure_acc(nbx_ctx* c) {
     c->variant = effective_variant(c);
     const int slices = slices_for(c, c->variant);
@@ -266,19 +292,10 @@ int ensure_acc(nbx_ctx* c) {
             c->qsum_slices_alloc = c->splits;
         }
         if (refine_active(c, c->variant) && !c->strict_list) {
-            // room for 1/16 of the shard (at least 16,384 targets): the default rule lists 0.3-0.8 % of uniform or Plummer 3D
-            // bodies and ~3 % of uniform 2D bodies.  As many strict slices (<= 256) as keep their fp64 partial sums within
-            // 256 MiB: a short list still spreads over the chip (one list block x 170-256 slices), a long one has the blocks.
-            c->strict_cap = c->pad / 16 > 16384u ? c->pad / 16 : 16384u;
-            if (c->strict_cap > c->pad) c->strict_cap = c->pad;
-            const unsigned tiles = (unsigned)c->n_shards * (c->pad / kTile);
-            size_t sl = kStrictAccBytesMax / ((size_t)c->dim * c->strict_cap * sizeof(double));
-            if (sl > 256) sl = 256;
-            if (sl > tiles) sl = tiles;
-            if (sl < 1) sl = 1;
-            c->strict_slices = (int)sl;
-            if ((rc = dev_alloc(c, &c->strict_list, (size_t)c->strict_cap * sizeof(unsigned)))) return rc;
-            if ((rc = dev_alloc(c, &c->strict_acc, (size_t)c->strict_slices * c->dim * c->strict_cap * sizeof(double)))) return rc;
+            size_t list_bytes = 0, acc_bytes = 0;
+            strict_sizes(c, &list_bytes, &acc_bytes);
+            if ((rc = dev_alloc(c, &c->strict_list, list_bytes))) return rc;
+            if ((rc = dev_alloc(c, &c->strict_acc, acc_bytes))) return rc;
         }
     }
     return NBX_OK;
@@ -291,6 +308,7 @@ RefineLaunch refine_launch(const nbx_ctx* c) {
     R.base.count = (unsigned)c->count; R.base.tgt_chunk = c->shard; R.base.splits = c->splits; R.base.n_chunks = c->n_shards;
     R.base.counters = c->counters; R.base.bad_flag = c->bad_flag; R.base.qsum = c->qsum;
     R.strict_list = c->strict_list; R.strict_acc = c->strict_acc; R.strict_cap = c->strict_cap; R.strict_slices = c->strict_slices;
+    R.strict_budget = c->strict_budget;
     const double r = (c->refine_sigma > 0.0 ? c->refine_sigma : c->dim == 2 ? kRefineSigmaDefault2D : kRefineSigmaDefault3D) * kUnitRoundoffF32 / c->refine_tol;
     R.c2 = r * r;
     R.grid_slices = c->splits;
@@ -457,6 +475,22 @@ int nbx_device_count(int* count) {
     return n > 0 ? NBX_OK : fail(NBX_ERR_NO_DEVICE, "hipGetDeviceCount returned 0 devices");
 }
 
+int nbx_set_default_refine(double rel_tolerance, double sigma_factor) {
+    const char* why = "";
+    if (!refine_args_ok(rel_tolerance, sigma_factor, &why)) return fail(NBX_ERR_INVALID, why);
+    g_default_refine_tol.store(rel_tolerance);
+    g_default_refine_sigma.store(sigma_factor);
+    return NBX_OK;
+}
+
+int nbx_get_default_refine(double* rel_tolerance, double* sigma_factor) {
+    if (rel_tolerance) *rel_tolerance = g_default_refine_tol.load();
+    if (sigma_factor) *sigma_factor = g_default_refine_sigma.load();
+    return NBX_OK;
+}
+
+double nbx_refine_sigma_default(int dim) { return dim == 2 ? kRefineSigmaDefault2D : kRefineSigmaDefault3D; }
+
 int nbx_release_cached(void) {
     release_parked_communicators();
     release_parked_leaf_arenas();
@@ -505,6 +539,8 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     c->pad = (unsigned)pad;
     c->variant = default_variant();
     c->variant_req = -1;
+    c->refine_tol = g_default_refine_tol.load();       // mixed mode unless the process default says plain fp32
+    c->refine_sigma = g_default_refine_sigma.load();
     { const char* e = std::getenv("NBODY_HIP_NO_GRAPHS"); c->no_graphs = e && *e && *e != '0'; }
 #define CTX_TRY(expr)                                                            \
     do {                                                                         \
@@ -530,6 +566,11 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
         want += 3 * arena_round(pad * sizeof(unsigned)) + arena_round((size_t)dim * pad * sizeof(float)) + arena_round(16)
                 + arena_round((size_t)dim * n_shards * pad * sizeof(float));
         if (n_shards == 1) want += arena_round((size_t)dim * pad * sizeof(float)) + arena_round(pad * sizeof(float));
+        if (c->refine_tol > 0.0) {   // mixed mode (the default): spread sums per slice, the list, the fp64 pass's sums
+            size_t list_bytes = 0, acc_bytes = 0;
+            strict_sizes(c, &list_bytes, &acc_bytes);
+            want += arena_round((size_t)splits * pad * sizeof(float)) + arena_round(list_bytes) + arena_round(acc_bytes);
+        }
         if (want <= ((size_t)64 << 30)) {   // beyond that the pieces are allocated one by one, and fail one by one
             void* a = nullptr;
             CTX_TRY(hipMalloc(&a, want));
@@ -545,6 +586,8 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
 #undef CTX_ALLOC
     c->ev0.assign(kEventPairs, nullptr);  // event pairs are created on first use
     c->ev1.assign(kEventPairs, nullptr);
+    c->ev2.assign(kEventPairs, nullptr);  // third mark of a mixed-mode evaluation: after its select / fp64 / fold kernels
+    c->ev2_set.assign(kEventPairs, 0);
 #undef CTX_TRY
     *out = c;
     return NBX_OK;
@@ -563,6 +606,7 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->bulk1) (void)hipEventDestroy(c->bulk1);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev2) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) {
         if (hipStreamSynchronize(c->own_stream) == hipSuccess) park_stream(c->device, c->own_stream);
         else (void)hipStreamDestroy(c->own_stream);
@@ -649,9 +693,8 @@ int nbx_ctx_set_law(nbx_ctx* c, int law) {
 
 int nbx_ctx_set_refine(nbx_ctx* c, double rel_tolerance, double sigma_factor) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
-    if (!(rel_tolerance == 0.0 || (rel_tolerance >= 1.0e-7 && rel_tolerance <= 1.0e-2)))
-        return fail(NBX_ERR_INVALID, "refine tolerance must be 0 (off) or in [1e-7, 1e-2]");
-    if (!(sigma_factor >= 0.0 && sigma_factor <= 1.0e6)) return fail(NBX_ERR_INVALID, "sigma factor must be 0 (default) or in (0, 1e6]");
+    const char* why = "";
+    if (!refine_args_ok(rel_tolerance, sigma_factor, &why)) return fail(NBX_ERR_INVALID, why);
     c->refine_tol = rel_tolerance;
     c->refine_sigma = sigma_factor;
     c->have_accel = false;
@@ -668,7 +711,7 @@ int nbx_ctx_refine_stats(nbx_ctx* c, unsigned* selected, unsigned* refined) {
     HIP_TRY(hipMemcpyAsync(&n, c->counters + 3, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (selected) *selected = n;
-    if (refined) *refined = n < c->strict_cap ? n : c->strict_cap;
+    if (refined) *refined = n;   // the list holds every target of the shard: whatever was selected was re-evaluated
     return NBX_OK;
 }
 
@@ -738,6 +781,7 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
             c->bulk_ms_done += ms;
+            if (c->ev2_set[i]) { HIP_TRY(hipEventElapsedTime(&ms, c->ev1[i], c->ev2[i])); c->refine_ms_done += ms; }
         }
         c->bulk_steps_done += c->ev_used;
         c->ev_used = 0;
@@ -747,18 +791,24 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
         HIP_TRY(hipEventCreate(&c->ev0[c->ev_used]));
         HIP_TRY(hipEventCreate(&c->ev1[c->ev_used]));
     }
-    if (timed) { L.ev_start = c->ev0[c->ev_used]; L.ev_stop = c->ev1[c->ev_used]; }
+    // mixed mode: once acc holds the sum over ALL sources (an ALL pass, or the REMOTE pass on top of LOCAL), the suspects
+    // are re-evaluated in fp64 against all chunks; a third event marks the end of that (nbx_ctx_refine_time)
+    const bool refine_now = refine && (which != NBX_SRC_LOCAL || c->n_shards == 1);
+    if (timed) { L.ev_start = c->ev0[c->ev_used]; L.ev_stop = c->ev1[c->ev_used]; c->ev2_set[c->ev_used] = 0; }
     HIP_TRY(launch_accel(c->dim, L, c->stream));
-    if (timed) ++c->ev_used;
     ++c->launches_since_query;
     c->have_accel = true;
     c->refined = false;
-    // mixed mode: once acc holds the sum over ALL sources (an ALL pass, or the REMOTE pass on top of LOCAL), the suspects
-    // are re-evaluated in fp64 against all chunks
-    if (refine && (which != NBX_SRC_LOCAL || c->n_shards == 1)) {
+    if (refine_now) {
         HIP_TRY(launch_refine(c->dim, refine_launch(c), c->stream));
+        if (timed) {
+            if (!c->ev2[c->ev_used]) HIP_TRY(hipEventCreate(&c->ev2[c->ev_used]));
+            HIP_TRY(hipEventRecord(c->ev2[c->ev_used], c->stream));
+            c->ev2_set[c->ev_used] = 1;
+        }
         c->refined = true;
     }
+    if (timed) ++c->ev_used;
     return NBX_OK;
 }
 
@@ -847,6 +897,9 @@ int nbx_ctx_step(nbx_ctx* c, double G, double dt, int nsteps) {
                 rc = poll_close_counters(c, block);
                 if (rc) return rc;
                 if (s < nsteps && (c->graph_hash != c->hash_refine || c->graph_variant != effective_variant(c))) {
+                    // the replays queued so far still use the executable graph and, possibly, buffers that ensure_acc is about to
+                    // give back: drain the stream first (a rare branch -- the close-set regime of the system changed)
+                    HIP_TRY(hipStreamSynchronize(c->stream));
                     rc = ensure_acc(c);
                     if (rc) return rc;
                     replay = capture_step(c, G, dt);   // false: the remaining steps run eagerly below
@@ -994,11 +1047,14 @@ int nbx_ctx_kernel_time(nbx_ctx* c, float* mean_ms, int* launches) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     double sum = 0.0;
+    double refine_sum = c->refine_ms_done;
     for (int i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
         sum += ms;
+        if (c->ev2_set[i]) { HIP_TRY(hipEventElapsedTime(&ms, c->ev1[i], c->ev2[i])); refine_sum += ms; }
     }
+    c->refine_ms_done = 0.0;
     int count = c->ev_used;
     if (c->bulk_steps) {  // graph-replayed steps: whole-step time (force kernel + the ~0.3 % of small kernels around it)
         float ms = 0.f;
@@ -1009,24 +1065,50 @@ int nbx_ctx_kernel_time(nbx_ctx* c, float* mean_ms, int* launches) {
     c->bulk_ms_done = 0.0; c->bulk_steps_done = 0;
     if (mean_ms) *mean_ms = count ? (float)(sum / count) : 0.f;
     if (launches) *launches = count;
+    c->last_refine_ms_total = refine_sum;
     c->ev_used = 0;
     c->launches_since_query = 0;
     return NBX_OK;
 }
 
+int nbx_ctx_refine_time(nbx_ctx* c, float* total_ms) {
+    if (!c || !total_ms) return fail(NBX_ERR_INVALID, "null argument");
+    *total_ms = (float)c->last_refine_ms_total;
+    return NBX_OK;
+}
+
 // ---- one-shot entry points -------------------------------------------------------------------------
 
-int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, double G, int device,
-                           double* forces_out, float* kernel_ms) {
+int nbx_brute_force_forces_ex(const void* bodies, size_t n, int dim, size_t stride_bytes, double G, int device,
+                              double rel_tolerance, double* forces_out, nbx_eval_info* info) {
     if ((!bodies || !forces_out) && n) return fail(NBX_ERR_INVALID, "null argument");
+    if (info) *info = nbx_eval_info{};
     nbx_ctx* c = nullptr;
     int rc = nbx_ctx_create(&c, device, dim, n, 1, 0);
     if (rc) return rc;
-    rc = nbx_ctx_upload_bodies(c, bodies, stride_bytes);
+    if (rel_tolerance >= 0.0) rc = nbx_ctx_set_refine(c, rel_tolerance, 0.0);   // < 0: the process default the context was made with
+    if (!rc) rc = nbx_ctx_upload_bodies(c, bodies, stride_bytes);
     if (!rc) rc = nbx_ctx_compute_accel(c, NBX_SRC_ALL);
     if (!rc) rc = nbx_ctx_get_forces(c, G, forces_out);
-    if (!rc && kernel_ms) rc = nbx_ctx_kernel_time(c, kernel_ms, nullptr);
+    if (!rc && info) {
+        rc = nbx_ctx_kernel_time(c, &info->kernel_ms, nullptr);
+        info->refine_ms = (float)c->last_refine_ms_total;
+        info->variant = c->variant;
+        if (!rc) rc = nbx_ctx_close_set_mode(c, &info->close_set_mode, nullptr, nullptr);
+        if (!rc && c->refined) {
+            info->refine_tolerance = c->refine_tol;
+            rc = nbx_ctx_refine_stats(c, &info->refine_selected, &info->refine_refined);
+        }
+    }
     nbx_ctx_destroy(c);
+    return rc;
+}
+
+int nbx_brute_force_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, double G, int device,
+                           double* forces_out, float* kernel_ms) {
+    nbx_eval_info info;
+    const int rc = nbx_brute_force_forces_ex(bodies, n, dim, stride_bytes, G, device, -1.0, forces_out, kernel_ms ? &info : nullptr);
+    if (!rc && kernel_ms) *kernel_ms = info.kernel_ms;
     return rc;
 }
 

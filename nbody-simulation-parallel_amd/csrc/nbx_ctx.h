@@ -50,8 +50,9 @@ struct nbx_ctx {
     int qsum_slices_alloc = 0;
     unsigned* strict_list = nullptr; // [strict_cap]
     double* strict_acc = nullptr;    // [strict_slices][dim][strict_cap]
-    unsigned strict_cap = 0;
-    int strict_slices = 0;
+    unsigned strict_cap = 0;         // = pad: room for every target of the shard
+    int strict_slices = 0;           // most source slices of the fp64 pass (the device may use fewer for a long list)
+    unsigned long long strict_budget = 0;   // doubles in strict_acc
     bool refined = false;            // the accelerations on the device went through the refinement
     float* phi = nullptr;        // [kPhiSlices][pad] potential partials (energy diagnostic)
     // one captured step {rebuild lists, force, scatter, kick+drift} replayed by nbx_ctx_step
@@ -87,7 +88,10 @@ struct nbx_ctx {
     double* stage = nullptr;
     size_t stage_bytes = 0;
     // kernel timing
-    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<hipEvent_t> ev0, ev1, ev2;   // around the force kernel; ev2: after the mixed mode's kernels of the same evaluation
+    std::vector<char> ev2_set;
+    double refine_ms_done = 0.0;        // mixed-mode time of evaluations already folded out of the event log
+    double last_refine_ms_total = 0.0;  // mixed-mode time of the evaluations the last nbx_ctx_kernel_time call covered
     int ev_used = 0;
     int launches_since_query = 0;
     int num_cus = 256;

@@ -135,9 +135,10 @@ struct KArgs {
     // mixed mode / strict kernel with listed targets
     float* __restrict__ qsum;          // [grid slices][pad] or null
     unsigned* __restrict__ strict_list;   // [strict_cap] targets to re-evaluate in fp64; their number is counters[3]
-    double* __restrict__ strict_acc;   // [strict slices][dim][strict_cap]
-    unsigned strict_cap;
-    int strict_slices;
+    double* __restrict__ strict_acc;   // [slices][dim][stride] with slices and stride chosen ON THE DEVICE from the list's length (strict_layout)
+    unsigned strict_cap;               // = the shard's pad: every target can be listed, nothing overflows
+    int strict_slices;                 // most source slices the fp64 pass may use (<= 256, <= total_tiles) = its gridDim.y
+    unsigned long long strict_budget;  // doubles in strict_acc: slices x dim x stride never exceeds it
     double refine_c2;                  // a target is listed when |a|^2 < refine_c2 * Q  (Q = sum over slices of qsum)
 };
 
@@ -181,6 +182,7 @@ struct RefineLaunch {
     double* strict_acc;
     unsigned strict_cap;
     int strict_slices;
+    unsigned long long strict_budget;
     double c2;
     int grid_slices;           // slices of the fast launch (planes of qsum)
 };

@@ -458,6 +458,23 @@ int nbx_node_set_refine(nbx_node* nd, double rel_tolerance, double sigma_factor)
     return NBX_OK;
 }
 
+int nbx_node_refine_stats(nbx_node* nd, unsigned* selected, unsigned* refined) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    unsigned sel = 0, ref = 0;
+    bool any = false;
+    for (Rank& k : nd->ranks) {
+        if (k.ctx->count == 0 || !k.ctx->refined) continue;
+        unsigned a = 0, b = 0;
+        int rc = nbx_ctx_refine_stats(k.ctx, &a, &b);
+        if (rc) return rc;
+        sel += a; ref += b; any = true;
+    }
+    if (!any) return fail(NBX_ERR_STATE, "no rank ran a mixed-mode evaluation");
+    if (selected) *selected = sel;
+    if (refined) *refined = ref;
+    return NBX_OK;
+}
+
 int nbx_node_compute_forces(nbx_node* nd, double G, double* forces_out) {
     if (!nd || (!forces_out && nd->n_total)) return fail(NBX_ERR_INVALID, "null argument");
     if (!nd->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");

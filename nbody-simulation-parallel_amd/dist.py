@@ -31,7 +31,7 @@ class HipShardBackend:
     """Shard compute on one MI355X: kernels via libnbody_hip.so, buffers and streams via torch."""
 
     def __init__(self, bodies: np.ndarray, layout: ShardLayout, device_index: int, variant: int = -1,
-                 source_splits: int = 0, refine_tol: float = 0.0):
+                 source_splits: int = 0, refine_tol: Optional[float] = None):
         if not torch.cuda.is_available():
             raise capi.NbxError(capi.NBX_ERR_NO_DEVICE, "HipShardBackend", "no GPU visible to torch; there is no CPU fallback")
         self.layout = layout
@@ -47,7 +47,7 @@ class HipShardBackend:
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self.ctx.set_stream(self.compute_stream.cuda_stream)
         self.ctx.set_tuning(source_splits, variant)
-        if refine_tol:
+        if refine_tol is not None:   # None: the library default (mixed mode, 1e-5); 0: plain fp32
             self.ctx.set_refine(refine_tol)   # mixed mode: the suspects of every evaluation re-evaluated in fp64 after the REMOTE pass
         torch.cuda.synchronize(self.device)  # zero fills done before the library's stream writes
         self.ctx.upload(bodies)
@@ -341,7 +341,7 @@ class ShardedNBody:
 
 
 def make_hip_system(bodies: np.ndarray, dim: int, rank: int = 0, world_size: int = 1, device_index: Optional[int] = None,
-                    group=None, variant: int = -1, source_splits: int = 0, refine_tol: float = 0.0, check_store=None) -> ShardedNBody:
+                    group=None, variant: int = -1, source_splits: int = 0, refine_tol: Optional[float] = None, check_store=None) -> ShardedNBody:
     layout = ShardLayout(n_total=bodies.shape[0], n_shards=world_size, shard=rank, dim=dim)
     be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits, refine_tol)
     return ShardedNBody(be, layout, group, check_store)

@@ -21,6 +21,9 @@
 // accelerations) on every body under the reference's law, F_i = -G m_i sum_j m_j (p_j-p_i)/r^4 with
 // pairs of r^2 < 1e-10 skipped.  Throws std::runtime_error on any device failure (the harness's
 // safely_execute, utils.h:95-103, then logs it and skips the row); there is no CPU fallback.
+// Precision: the reference computes in fp64 (vector.h:9-12); the device runs the library's MIXED MODE by default --
+// fp32 pair terms for every body, an fp64 re-evaluation of the bodies whose fp32 sum cannot be trusted -- so that every
+// body's force is within 1e-5 relative of the sequential reference's on the same inputs.  set_hip_refine() changes that.
 template <int D>
 std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies);
 
@@ -66,8 +69,11 @@ double brute_force_hip_accuracy(const std::vector<Body<D>>& bodies, const std::v
 
 // Timing of the most recent call on this thread, for pair-interactions/s and roofline reporting.
 struct HipRunInfo {
-    float kernel_ms = 0.0f;   // force-kernel time only (hipEvent), summed over the call's launches
+    float kernel_ms = 0.0f;   // device time of the force evaluation(s) (hipEvent), summed over the call's launches
     int device = 0;
+    double refine_tolerance = 0.0;     // mixed mode's relative tolerance in force during the call (0: plain fp32)
+    unsigned refine_selected = 0;      // targets the mixed mode listed in the call's (last) force evaluation ...
+    unsigned refine_refined = 0;       // ... and re-evaluated in fp64 (always the same number: nothing overflows)
 };
 const HipRunInfo& last_hip_run_info();
 
@@ -76,6 +82,11 @@ const HipRunInfo& last_hip_run_info();
 bool warm_up_hip();
 // Give back what the library keeps between calls (idle streams, RCCL communicators): nbx_release_cached.  Before exit.
 void release_hip_caches();
+
+// Precision of every HIP entry point from now on (nbx_set_default_refine): rel_tolerance = 0 is plain fp32, otherwise the
+// mixed mode's per-body relative tolerance.  The library's default is 1e-5.  Throws on an out-of-range tolerance.
+void set_hip_refine(double rel_tolerance);
+double hip_refine_tolerance();
 
 // Number of HIP devices visible (0 when there is none or the runtime fails).
 int hip_device_count();

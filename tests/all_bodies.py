@@ -5,7 +5,8 @@ The CPU oracle cannot visit all N^2 pairs at N = 2^20 in test time (11 minutes o
 strict fp64 kernel -- the reference's arithmetic type on the same fp32-representable inputs -- is first pinned to the oracle on
 >= 1,024 sampled rows (every pair of those rows, `oracle_force_rows_omp_2`), and then serves as the yardstick for ALL bodies:
 relative error |dF_i|/|F_i| and backward error |dF_i|/S_i (S_i = sum_j |f_ij|, from the same strict launch's magnitude-sum
-build) of the default fp32 path and of the mixed mode."""
+build) of the plain fp32 path (nbx_ctx_set_refine(0); record key "default" for continuity with round 3's records) and of the
+mixed mode (the library's default precision since ABI 4)."""
 import json
 import os
 import time
@@ -62,6 +63,7 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
     rec = dict(what=label, n=n, dim=dim, sampled_rows=int(sample.size))
     with nbx.Context(n, dim) as c:
         c.upload(bodies)
+        c.set_refine(0.0)   # a new context starts in the library's default precision (mixed mode): "default fp32" below means plain
         # 1. strict kernel (+ magnitude sums), pinned to the oracle on the sampled rows
         c.set_tuning(0, _variant(nbx, "strict_f64_t4_mag"))
         rec["strict_mag_ms"] = _timed(c, 1)

@@ -13,7 +13,7 @@ rows = np.unique(np.random.default_rng(0).integers(0, n, 48))
 ref = o.force_rows_omp_2(b, rows); S = o.force_magnitude_sums(b, rows)
 with nbx.Context(n, 3) as c:
     c.upload(b); c.compute_accel(); f = c.forces(o.G); ms, _ = c.kernel_time()
-    print("N=2^22 1 GPU:", c.effective_tuning(), f"{ms:.1f} ms  {n*n/ms*1e3:.3e} pairs/s", assert_force_parity(f[rows], ref, S, "N=2^22"), flush=True)
+    print("N=2^22 1 GPU:", c.effective_tuning(), f"{ms:.1f} ms  {n*n/ms*1e3:.3e} pairs/s", assert_force_parity(f[rows], ref, S, "N=2^22", n_sources=n), flush=True)
 with nbx.Context(n, 3, n_shards=8, shard=3) as c:
     c.upload(b); c.compute_accel(nbx.SRC_LOCAL); c.compute_accel(nbx.SRC_REMOTE); fs = c.forces(o.G); ms, cnt = c.kernel_time()
     lo = 3 * c.shard_len

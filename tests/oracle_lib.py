@@ -277,6 +277,11 @@ def have_reference() -> bool:
 TOL_REL = 1.0e-5
 TOL_BACKWARD = 1.0e-5
 KAPPA_WELL = 4.0
+# (T1) is sized on systems of millions of bodies.  Sums over at most 65,536 sources were held to 4e-6 in round 2 (largest seen:
+# 2.1e-6); a regression of the kernels at that size must not hide behind the million-body constant, so assert_force_parity keeps
+# the round-2 bound there (round 3's ADVICE).  All four constants are pinned by tests/test_tolerances_frozen.py.
+TOL_BACKWARD_SMALL_N = 4.0e-6
+SMALL_N = 65536
 
 
 def force_errors(forces, ref_forces, magnitude_sums):
@@ -295,10 +300,14 @@ def force_errors(forces, ref_forces, magnitude_sums):
                 n_ill=int((live & ~well).sum()), n=int(live.sum()))
 
 
-def assert_force_parity(forces, ref_forces, magnitude_sums, what=""):
+def assert_force_parity(forces, ref_forces, magnitude_sums, what="", n_sources=None):
+    """(T1) + (T2).  n_sources: bodies each compared sum ran over (default: as many as there are rows -- callers that compare
+    sampled rows of a larger system say so); up to SMALL_N sources (T1) is held at TOL_BACKWARD_SMALL_N."""
     e = force_errors(forces, ref_forces, magnitude_sums)
     assert np.isfinite(forces).all(), f"{what}: non-finite device forces"
-    assert e["max_backward"] <= TOL_BACKWARD, f"{what}: backward error {e['max_backward']:.3e} > {TOL_BACKWARD} ({e})"
+    n_sources = np.asarray(forces).shape[0] if n_sources is None else n_sources
+    tol_back = TOL_BACKWARD_SMALL_N if n_sources <= SMALL_N else TOL_BACKWARD
+    assert e["max_backward"] <= tol_back, f"{what}: backward error {e['max_backward']:.3e} > {tol_back} ({e})"
     assert e["max_rel_well"] <= TOL_REL, f"{what}: relative error {e['max_rel_well']:.3e} > {TOL_REL} on well-conditioned bodies ({e})"
     return e
 

@@ -51,7 +51,7 @@ def test_config5_context_n4194304(nbx, oracle):
         f = c.forces(oracle.G)[rows]
         ms, _ = c.kernel_time()
         ref = oracle.force_rows_omp_2(b, rows)
-        e = assert_force_parity(f, ref, oracle.force_magnitude_sums(b, rows), "config 5 initial state")
+        e = assert_force_parity(f, ref, oracle.force_magnitude_sums(b, rows), "config 5 initial state", n_sources=N)
         worst = float((np.linalg.norm(f - ref, axis=1) / np.linalg.norm(ref, axis=1)).max())
         # energy before / after STEPS device-resident steps
         ke0, pe0 = c.energy(G5)

@@ -49,7 +49,7 @@ def test_hip_only_large_n_and_leapfrog(tmp_path, oracle):
     rows = np.arange(0, n, n // 64)
     f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
     br = oracle.round_inputs_to_f32(bodies)
-    assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "harness sampled rows")
+    assert_force_parity(f[rows], oracle.force_rows_omp_2(br, rows), oracle.force_magnitude_sums(br, rows), "harness sampled rows", n_sources=n)
 
 
 def test_device_side_accuracy_in_the_harness(tmp_path):
@@ -184,3 +184,39 @@ def test_run_config5_script_rehearsal(tmp_path):
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     summary = open(tmp_path / "c5.summary.txt").read()
     assert summary.count("|dE/E0|") == 2 and "Time taken" in summary, summary
+
+
+def test_every_body_of_the_harness_row_at_n1048576(tmp_path, nbx, oracle):
+    """The path a maintainer binds, at BASELINE's headline size, for EVERY body: `nbody_sim -N 1048576 -m g --dump` runs
+    brute_force_hip_n_body<3> (C++ wrapper -> C ABI, the library's default precision = mixed mode, call shape of
+    nbody-sim-new/main.cpp:137-140) and dumps bodies and forces; the strict fp64 kernel (the reference's arithmetic type,
+    methods.cpp:21-37, pinned to the oracle on sampled rows here) evaluates the same bodies, and every one of the 1,048,576
+    forces of the harness row lies within 1e-5 relative of it.  `--refine 0` (plain fp32) on the same bodies leaves some
+    bodies above the tolerance -- the difference the default makes -- and the harness says which mode ran."""
+    import re
+    n = 1 << 20
+    p = _run(tmp_path, "-N", str(n), "-m", "g", "--seed", "1", "--dump", "d")
+    assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    m = re.search(r"Precision: mixed mode, per-body relative tolerance 1.0e-05: (\d+) of 1048576 bodies listed by the selection rule, (\d+) re-evaluated", p.stdout)
+    assert m and int(m.group(1)) == int(m.group(2)) > 0, p.stdout[-1500:]
+    bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
+    f = np.fromfile(os.path.join(tmp_path, "d_BruteForce_HIP.f64")).reshape(n, 3)
+    with nbx.Context(n, 3) as c:
+        c.upload(bodies)
+        c.set_tuning(0, nbx.variants().index("strict_f64_t4"))
+        c.compute_accel()
+        fs = c.forces(oracle.G)
+    br = oracle.round_inputs_to_f32(bodies)
+    rows = np.unique(np.random.default_rng(5).integers(0, n, 1100))
+    ref = oracle.force_rows_omp_2(br, rows)
+    d = np.sqrt(((fs[rows] - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
+    assert d.max() <= 1e-9, f"strict kernel vs oracle rows: {d.max():.3e}"
+    rel = np.sqrt(((f - fs) ** 2).sum(axis=1)) / np.sqrt((fs ** 2).sum(axis=1))
+    print(f"\n  harness row, all {n} bodies vs the strict kernel: max rel {rel.max():.3e}, over 1e-5: {(rel > 1e-5).sum()}, listed {m.group(1)}")
+    assert rel.max() <= 1e-5, f"{(rel > 1e-5).sum()} bodies above 1e-5, worst {rel.max():.3e}"
+    q = _run(tmp_path, "-N", str(n), "-m", "g", "--seed", "1", "--refine", "0", "--dump", "p")
+    assert q.returncode == 0 and "Precision: plain fp32" in q.stdout, q.stdout[-1500:]
+    fp = np.fromfile(os.path.join(tmp_path, "p_BruteForce_HIP.f64")).reshape(n, 3)
+    relp = np.sqrt(((fp - fs) ** 2).sum(axis=1)) / np.sqrt((fs ** 2).sum(axis=1))
+    print(f"  --refine 0: max rel {relp.max():.3e}, over 1e-5: {(relp > 1e-5).sum()}")
+    assert (f != fp).any(axis=1).sum() <= int(m.group(1))   # the two rows differ on listed bodies only

@@ -127,6 +127,7 @@ def test_mixed_mode_small_systems(nbx, oracle):
         ref, S = oracle.brute_force_seq(b), oracle.force_magnitude_sums(b)
         with nbx.Context(n, dim) as c:
             c.upload(b)
+            c.set_refine(0.0)
             c.compute_accel()
             plain = c.forces(oracle.G)
             c.set_refine(1e-5)
@@ -141,7 +142,7 @@ def test_mixed_mode_small_systems(nbx, oracle):
             assert changed.sum() <= sel, "only listed targets may change"
             assert (e_mixed[changed] <= 1e-7).all(), "re-evaluated targets come back in fp64 (rounded to the hi/lo planes)"
             assert e_mixed.max() <= max(e_plain.max(), 1e-7)
-            c.set_refine(1e-7, 1e6)   # every target is a suspect: capacity is 4096 >= n here
+            c.set_refine(1e-7, 1e6)   # every target is a suspect
             c.compute_accel()
             sel, done = c.refine_stats()
             assert sel == n and done == n
@@ -211,10 +212,12 @@ def test_every_body_of_config5_n4194304(nbx, oracle):
     assert rec["mixed"]["refined"] == rec["mixed"]["selected"] <= n // 50, rec["mixed"]
 
 
-def test_mixed_mode_capacity_overflow_and_node_layer(nbx, oracle):
-    """More suspects than the re-evaluation holds (capacity = max(16,384, 1/16 of the shard)): the first `capacity` listed
-    targets come back in fp64, the others keep their fp32 result, the counts say so, nothing is lost or written twice.  And the
-    single-process node layer (nbx_node_set_refine: every rank refines its own shard after its REMOTE pass)."""
+def test_mixed_mode_long_lists_and_node_layer(nbx, oracle):
+    """There is no capacity to overflow (round 3 re-evaluated at most max(16,384, shard/16) targets and said so only in
+    nbx_ctx_refine_stats): the list has room for every target of the shard and the fp64 pass picks its source slices on the device
+    from the list's length.  With EVERY target of a 40,000-body system listed -- 157 list blocks, the buffer's budget then allows
+    fewer slices than a short list gets -- every body comes back at fp64 quality, nothing lost or written twice.  And the
+    single-process node layer (nbx_node_set_refine / nbx_node_refine_stats: every rank refines its own shard after its REMOTE pass)."""
     n, dim = 40000, 3
     b = _inputs(oracle, 55, n, dim)
     rows = np.arange(0, n, 13)
@@ -222,23 +225,85 @@ def test_mixed_mode_capacity_overflow_and_node_layer(nbx, oracle):
     S = oracle.force_magnitude_sums(b, rows)
     with nbx.Context(n, dim) as c:
         c.upload(b)
+        c.set_refine(0.0)
         c.compute_accel()
         plain = c.forces(oracle.G)
         c.set_refine(1e-7, 1e6)                     # every target is a suspect
         c.compute_accel()
         sel, done = c.refine_stats()
         mixed = c.forces(oracle.G)
-    assert sel == n and done == 16384, (sel, done)
+        c.set_tuning(0, nbx.variants().index(STRICT))
+        c.compute_accel()
+        strict = c.forces(oracle.G)
+    assert sel == n and done == n, (sel, done)
     changed = (mixed != plain).any(axis=1)
-    assert 16000 <= changed.sum() <= 16384          # (a re-evaluated target may happen to round to the same fp32-plane pair)
-    e = np.sqrt(((mixed[rows] - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
-    assert (e[changed[rows]] <= 1e-7).all() and (e <= 1e-5).all()
-    from oracle_lib import assert_force_parity
-    assert_force_parity(mixed[rows], ref, S, "capacity overflow")
+    assert changed.sum() >= n - 400                 # (a re-evaluated target may happen to round to the same fp32-plane pair)
+    _assert_strict(mixed[rows], ref, S, "every target listed")
+    # against the whole-chunk strict kernel on ALL bodies: same arithmetic, one Newton step less and another slice order
+    d = np.sqrt(((mixed - strict) ** 2).sum(axis=1)) / np.sqrt((strict ** 2).sum(axis=1))
+    assert d.max() <= 1e-9, d.max()
+    for dim2, n2 in ((2, 9000), (3, 300000)):       # 2D; and a list of 1,172 blocks: each of the 32 workgroup rows walks ~37 of them
+        bb = _inputs(oracle, 57 + dim2, n2, dim2)
+        with nbx.Context(n2, dim2) as c:
+            c.upload(bb)
+            c.set_refine(1e-7, 1e6)
+            c.compute_accel()
+            assert c.refine_stats() == (n2, n2)
+            mixed = c.forces(oracle.G)
+            c.set_tuning(0, nbx.variants().index(STRICT))
+            c.compute_accel()
+            strict = c.forces(oracle.G)
+        d = np.sqrt(((mixed - strict) ** 2).sum(axis=1)) / np.sqrt((strict ** 2).sum(axis=1))
+        assert d.max() <= 1e-9, (dim2, n2, d.max())
     m = 6000
     bb = _inputs(oracle, 56, m, dim)
     with nbx.Node(m, dim, [0, 0, 0]) as node:
         node.upload(bb)
         node.set_refine(1e-7, 1e6)
         f = node.forces(oracle.G)
+        assert node.refine_stats() == (m, m)
     _assert_strict(f, oracle.brute_force_seq(bb), oracle.force_magnitude_sums(bb), "node layer, all targets refined")
+
+
+def test_mixed_mode_is_the_default_precision(nbx, oracle):
+    """ABI 4: every entry point a maintainer binds runs the mixed mode unless told otherwise -- a new context, the one-shot
+    call (nbx_brute_force_forces = nbx_brute_force_forces_ex with rel_tolerance < 0), the node layer; nbx_set_default_refine
+    changes it process-wide for what is created afterwards.  On a 2D input (plane sums cancel hard: dozens of suspects at this
+    size) the default result equals the explicit 1e-5 one bit for bit and differs from plain fp32 on listed bodies only."""
+    assert nbx.get_default_refine() == (1e-5, 0.0)
+    n, dim = 30000, 2
+    b = _inputs(oracle, 91, n, dim)
+    f_default, info = nbx.brute_force_hip_n_body(b, oracle.G, return_info=True)
+    assert info.refine_tolerance == 1e-5 and info.refine_selected == info.refine_refined > 0 and info.refine_ms > 0
+    f_explicit = nbx.brute_force_hip_n_body(b, oracle.G, rel_tolerance=1e-5)
+    f_plain, info0 = nbx.brute_force_hip_n_body(b, oracle.G, rel_tolerance=0.0, return_info=True)
+    assert info0.refine_tolerance == 0.0 and info0.refine_selected == 0
+    assert np.array_equal(f_default, f_explicit)
+    changed = (f_default != f_plain).any(axis=1)
+    assert 0 < changed.sum() <= info.refine_selected
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.compute_accel()
+        assert c.refine_stats() == (info.refine_selected, info.refine_selected)
+        assert np.array_equal(c.forces(oracle.G), f_default)
+    with nbx.Node(n, dim, [0, 0]) as node:
+        node.upload(b)
+        node.forces(oracle.G)
+        assert node.refine_stats()[0] > 0
+    try:
+        nbx.set_default_refine(0.0)
+        assert nbx.get_default_refine() == (0.0, 0.0)
+        assert np.array_equal(nbx.brute_force_hip_n_body(b, oracle.G), f_plain)
+        with nbx.Context(n, dim) as c:
+            c.upload(b)
+            c.compute_accel()
+            with pytest.raises(nbx.NbxError):
+                c.refine_stats()
+        with pytest.raises(nbx.NbxError):
+            nbx.set_default_refine(0.5)
+    finally:
+        nbx.set_default_refine(1e-5)
+    # every body of this input within the tolerance in the default precision (oracle: the sequential reference on the same inputs)
+    ref = oracle.brute_force_seq(b)
+    rel = np.sqrt(((f_default - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
+    assert rel.max() <= TOL_REL, rel.max()
