@@ -134,14 +134,49 @@ int nbx_leapfrog(void* bodies, size_t n, int dim, size_t body_stride_bytes,
  *                          r^2 < 1e-10 the magnitude uses r^2 + (1e-5)^2 while the direction stays d/|d|
  * forces_out: n x Vector<dim>, zero for bodies in no leaf.  fp32 pair terms on leaf-ordered source pairs, fp64 sums;
  * every index array is validated on the host before anything is launched (NBX_ERR_INVALID).  kernel_ms (optional)
- * receives the pair kernel's duration (hipEvent).  Measurement aid: with NBX_LEAF_TIMING_REPS=R (2..1000) in the
- * environment the pair kernel is launched R times back to back (same sums every time) and kernel_ms is the mean of the
- * second half of the launches -- the duration with the clocks up, which one launch after the call's copies does not see. */
+ * receives the pair kernel's duration (hipEvent).  This one-shot form validates, lays out and uploads the structure on every
+ * call; a tree code that evaluates its leaf sums every step from resident bodies uses the PLAN below. */
 enum { NBX_LAW_BRUTE = 0, NBX_LAW_TREE_LEAF = 1, NBX_LAW_FMM_P2P = 2 };
 int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
                          const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
                          const uint32_t* list_offsets, const uint32_t* list_sources,
                          int law, double G, int device, double* forces_out, float* kernel_ms);
+
+/* ---- device-resident leaf plan ---------------------------------------------------------------------------------------
+ * The reference's tree codes evaluate their leaf sums in EVERY force evaluation, from bodies that stay where they are
+ * (bvh.cpp:143-176 BVH::calculate_force per body over the leaves its traversal accepts; fmm_parlay.cpp:916-1022 p2p_phase per
+ * step) while the leaf structure changes only when the tree is rebuilt.  A plan is that structure made resident: the CSR
+ * arrays are validated ONCE, the launch is laid out once (leaf-ordered slots, copy runs, workgroup table: csrc/leaf_plan.h)
+ * and stays on `device` with the buffers the kernels need; each evaluation then only re-gathers positions and runs the pair
+ * kernel.  Arguments as for nbx_leaf_pair_forces.  A plan is bound to its device, dim and body count; not thread-safe. */
+typedef struct nbx_leaf_plan nbx_leaf_plan;
+int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n_bodies,
+                         const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
+                         const uint32_t* list_offsets, const uint32_t* list_sources);
+int nbx_leaf_plan_destroy(nbx_leaf_plan* plan);
+/* Host bodies in, host forces out (n_bodies x Vector<dim>; zero for bodies in no leaf): one H2D copy of the Body<dim> array,
+ * gather, pair kernel, one D2H copy.  kernel_ms (optional): the pair kernel's duration. */
+int nbx_leaf_plan_forces(nbx_leaf_plan* plan, const void* bodies, size_t body_stride_bytes, int law, double G,
+                         double* forces_out, float* kernel_ms);
+/* Bodies RESIDENT on the device: positions and masses are gathered from `ctx` (a single-shard context of n_bodies bodies on
+ * the plan's device, dim as the plan's; its fp32 source copy as it stands after the last upload / kick-drift), everything is
+ * ordered on the context's stream.  forces_out may be NULL: the sums then stay on the device for nbx_leaf_plan_get_forces /
+ * nbx_leaf_plan_kick_drift and the call does not wait for the device (kernel_ms must be NULL too).  With forces_out or
+ * kernel_ms the call synchronises the stream. */
+int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* plan, nbx_ctx* ctx, int law, double G, double* forces_out, float* kernel_ms);
+/* Forces of the last evaluation (n_bodies x Vector<dim>) -- F = +-(G m_i) x the leaf sums, the law's sign.  Synchronises. */
+int nbx_leaf_plan_get_forces(nbx_leaf_plan* plan, double* forces_out);
+/* update_body_velocities + update_body_positions (methods.cpp:425-450) of `ctx`'s bodies from the LAST evaluation's leaf sums
+ * (law and G as given there), fp64, the arithmetic of nbx_ctx_kick_drift; bodies in no leaf drift with their velocity.
+ * Asynchronous on the context's stream.  This is the stepping loop of a tree code whose far field is zero: what `nbody_sim
+ * -m p --steps k` runs. */
+int nbx_leaf_plan_kick_drift(nbx_leaf_plan* plan, nbx_ctx* ctx, double dt);
+/* MEASUREMENT entry (tools/, bench.py): the pair kernel launched `reps` times back to back on the bodies of the last
+ * evaluation (same sums every time); mean_ms = mean duration of the second half of the launches -- the kernel with the clocks
+ * up, which a single launch from idle does not see.  1 <= reps <= 1000.  Synchronises. */
+int nbx_leaf_plan_time_kernel(nbx_leaf_plan* plan, int law, int reps, float* mean_ms);
+/* Counts of the layout: padded slots, copy runs, workgroups, wave64 per workgroup (any pointer may be NULL). */
+int nbx_leaf_plan_info(const nbx_leaf_plan* plan, size_t* slots, size_t* runs, size_t* workgroups, int* waves_per_workgroup);
 
 /* ---- device-resident context ------------------------------------------------------------------
  * A context owns the targets of ONE shard of an N-body system on ONE device and a full-length

@@ -12,7 +12,7 @@ through the root-level shim:  `import nbody_amd as nbx`  (or importlib with the 
 from .capi import (  # noqa: F401
     ABI, EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, LIB_PATH, REFERENCE_G, SRC_ALL, SRC_LOCAL, SRC_REMOTE,
     FORCE_LAW_NEWTON, FORCE_LAW_REFERENCE, LAW_BRUTE, LAW_FMM_P2P, LAW_TREE_LEAF,
-    Context, EvalInfo, NbxError, Node,
+    Context, EvalInfo, LeafPlan, NbxError, Node,
     get_default_refine, refine_sigma_default, set_default_refine,
     body_stride, brute_force_hip_n_body, device_count, leaf_pair_forces_hip, leapfrog_hip_n_body, load_library, variants,
 )

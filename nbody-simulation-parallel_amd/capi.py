@@ -41,6 +41,14 @@ ABI = [
     ("nbx_brute_force_forces_ex", _i, [_vp, _sz, _i, _sz, _d, _i, _d, _vp, _vp]),
     ("nbx_leapfrog", _i, [_vp, _sz, _i, _sz, _d, _d, _i, _i, _pf]),
     ("nbx_leaf_pair_forces", _i, [_vp, _sz, _i, _sz, _vp, _vp, _sz, _vp, _vp, _i, _d, _i, _vp, _pf]),
+    ("nbx_leaf_plan_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _vp, _vp, _sz, _vp, _vp]),
+    ("nbx_leaf_plan_destroy", _i, [_vp]),
+    ("nbx_leaf_plan_forces", _i, [_vp, _vp, _sz, _i, _d, _vp, _pf]),
+    ("nbx_leaf_plan_forces_ctx", _i, [_vp, _vp, _i, _d, _vp, _pf]),
+    ("nbx_leaf_plan_get_forces", _i, [_vp, _vp]),
+    ("nbx_leaf_plan_kick_drift", _i, [_vp, _vp, _d]),
+    ("nbx_leaf_plan_time_kernel", _i, [_vp, _i, _i, _pf]),
+    ("nbx_leaf_plan_info", _i, [_vp, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz), _pi]),
     ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),
     ("nbx_ctx_destroy", _i, [_vp]),
     ("nbx_ctx_set_stream", _i, [_vp, _vp]),
@@ -237,6 +245,84 @@ def leaf_pair_forces_hip(bodies: np.ndarray, leaf_offsets, leaf_bodies, list_off
                                          arrs[0].size - 1, arrs[2].ctypes.data, arrs[3].ctypes.data, law, G, device,
                                          out.ctypes.data, ctypes.byref(ms)), "nbx_leaf_pair_forces")
     return (out, ms.value) if return_kernel_ms else out
+
+
+class LeafPlan:
+    """Device-resident leaf structure of a tree code (nbx_leaf_plan_* of include/nbody_hip.h): the CSR arrays are validated,
+    laid out and uploaded once; every evaluation re-gathers positions (from host bodies, or from a resident Context) and runs the
+    pair kernel -- the call pattern of bvh.cpp:143-176 / fmm_parlay.cpp:916-1022, whose trees stand while the bodies move."""
+
+    def __init__(self, n_bodies: int, dim: int, leaf_offsets, leaf_bodies, list_offsets, list_sources, device: int = 0):
+        self.lib = load_library()
+        self.n, self.dim, self.device = int(n_bodies), int(dim), device
+        arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (leaf_offsets, leaf_bodies, list_offsets, list_sources)]
+        if arrs[0].size < 1 or arrs[2].size != arrs[0].size:
+            raise ValueError("leaf_offsets and list_offsets must both have n_leaves + 1 entries")
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.nbx_leaf_plan_create(ctypes.byref(h), device, dim, self.n, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                                       arrs[0].size - 1, arrs[2].ctypes.data, arrs[3].ctypes.data), "nbx_leaf_plan_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbx_leaf_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc, where):
+        _check(self.lib, rc, where)
+
+    def info(self):
+        """(padded slots, copy runs, workgroups, wave64 per workgroup) of the resident layout."""
+        a, b, c, w = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_int()
+        self._ck(self.lib.nbx_leaf_plan_info(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(w)), "nbx_leaf_plan_info")
+        return a.value, b.value, c.value, w.value
+
+    def forces(self, bodies: np.ndarray, law: int = 2, G: float = REFERENCE_G, return_kernel_ms: bool = False):
+        """Host bodies in, host forces out (nbx_leaf_plan_forces)."""
+        b, dim = _as_bodies(bodies)
+        if dim != self.dim or b.shape[0] != self.n:
+            raise ValueError("bodies shape does not match the plan")
+        out = np.empty((self.n, dim), dtype=np.float64)
+        ms = ctypes.c_float(0.0)
+        self._ck(self.lib.nbx_leaf_plan_forces(self.h, b.ctypes.data, b.shape[1] * 8, law, G, out.ctypes.data, ctypes.byref(ms)), "nbx_leaf_plan_forces")
+        return (out, ms.value) if return_kernel_ms else out
+
+    def forces_ctx(self, ctx: "Context", law: int = 2, G: float = REFERENCE_G, fetch: bool = True, timed: bool = False):
+        """Bodies resident in `ctx` (nbx_leaf_plan_forces_ctx).  fetch=False: the sums stay on the device (asynchronous unless
+        timed); returns forces, (forces, kernel_ms), kernel_ms or None accordingly."""
+        out = np.empty((self.n, self.dim), dtype=np.float64) if fetch else None
+        ms = ctypes.c_float(0.0)
+        self._ck(self.lib.nbx_leaf_plan_forces_ctx(self.h, ctx.h, law, G, out.ctypes.data if fetch else None,
+                                                   ctypes.byref(ms) if timed else None), "nbx_leaf_plan_forces_ctx")
+        if fetch:
+            return (out, ms.value) if timed else out
+        return ms.value if timed else None
+
+    def get_forces(self) -> np.ndarray:
+        out = np.empty((self.n, self.dim), dtype=np.float64)
+        self._ck(self.lib.nbx_leaf_plan_get_forces(self.h, out.ctypes.data), "nbx_leaf_plan_get_forces")
+        return out
+
+    def kick_drift(self, ctx: "Context", dt: float):
+        self._ck(self.lib.nbx_leaf_plan_kick_drift(self.h, ctx.h, float(dt)), "nbx_leaf_plan_kick_drift")
+
+    def time_kernel(self, law: int, reps: int) -> float:
+        """Measurement: mean ms of the second half of `reps` back-to-back launches of the pair kernel."""
+        ms = ctypes.c_float(0.0)
+        self._ck(self.lib.nbx_leaf_plan_time_kernel(self.h, law, reps, ctypes.byref(ms)), "nbx_leaf_plan_time_kernel")
+        return ms.value
 
 
 class Context:

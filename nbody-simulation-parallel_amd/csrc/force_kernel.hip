@@ -521,6 +521,133 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Three-level fast kernel (round 4): the same packed pair arithmetic, a summation that keeps fp32 errors 2-3x smaller.
+// Where the two-level kernel's error comes from: a term rides through up to 255 fp32 additions of its
+// 256-source tile and then up to 256 flushes into an fp32 slice sum that has grown to the whole slice's partial sum -- the two
+// levels contribute about equally, and a body whose pulls cancel to a hundredth of their size ends up 1e-5 to 3e-5 off.  Here
+//   level 1: fp32 sums over LB = 64 (or 32) sources in registers (ax), flushed into
+//   level 2: the fp32 sum of ONE 256-source tile (ox; 256/LB flushes), flushed once per tile into
+//   level 3: fp64 slice sums that live in LDS (48 KB per workgroup: 8 targets x 3 components x 256 lanes; each lane touches only
+//            its own 24 slots, 12 ds_read_b128 + 24 v_cvt_f64_f32 + 24 v_add_f64 + 12 ds_write_b128 per 13,568 VALU of pair work),
+// and a slice's fp64 sum leaves as TWO fp32 planes (hi, lo), like the strict kernel's: no consumer knows.  Rounding now happens
+// relative to partial sums of at most 64 terms (level 1) and 256 terms (level 2): variance ~ (32 + 2.5) a_p^2 per source against
+// (128 + 128) -- errors 2.7x smaller at +12 v_pk_add per 64 sources (+0.35 %).  Register budget unchanged (the slice sums left
+// the registers), 3 waves per SIMD; LDS 52 KB per workgroup x 3 workgroups per CU = 156 of 160 KB, which is why the source tile
+// is SINGLE-buffered here (two barriers per tile instead of one; the three workgroups of a CU cover each other's waits).
+// QS = 1: Q_i = sum over the LEVEL-1 blocks of |block sum|^2 (the running sums whose roundings dominate), one plane per slice.
+// -------------------------------------------------------------------------------------------------
+template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS>
+__global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
+    constexpr int TPL = 2 * PAIRS;
+    static_assert(kTile % LB == 0 && LB % UNROLL == 0, "level-1 blocks tile the source tile");
+    constexpr unsigned kSumBytes = (unsigned)PAIRS * D * 256u * sizeof(double2);   // [PAIRS*D][256] double2 = the two targets of a pair
+    static_assert(2 * kTile * sizeof(float4) <= kSumBytes, "the close-set path's double-buffered tile aliases the slice sums");
+    __shared__ __attribute__((aligned(16))) char smem[kTile * sizeof(float4) + kSumBytes];
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(bx, by);
+    if (bx < a.close_blocks) {   // the launch's extra workgroups: guarded evaluation of the close set (they keep no slice sums)
+        close_set_path<D>(a, *reinterpret_cast<float4 (*)[2][kTile]>(smem + kTile * sizeof(float4)), bx, by);
+        return;
+    }
+    float4* __restrict__ tile = reinterpret_cast<float4*>(smem);
+    double2* __restrict__ sums = reinterpret_cast<double2*>(smem + kTile * sizeof(float4));
+    const f2 bias = f2{kTiny, kTiny};
+    const unsigned tid = threadIdx.x;
+    const unsigned tgt0 = (bx - a.close_blocks) * (256u * TPL) + tid;
+    const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
+
+    f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], qq[QS ? PAIRS : 1];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const unsigned i0 = tgt0 + (2 * q) * 256u, i1 = i0 + 256u;
+        ix[q] = f2{tp[i0], tp[i1]};
+        iy[q] = f2{tp[(size_t)a.pad + i0], tp[(size_t)a.pad + i1]};
+        iz[q] = (D == 3) ? f2{tp[2 * (size_t)a.pad + i0], tp[2 * (size_t)a.pad + i1]} : f2{0.f, 0.f};
+        if (QS) qq[q] = f2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < PAIRS * D; ++c) sums[c * 256 + tid] = double2{0.0, 0.0};   // own slots only: no barrier needed
+
+    unsigned t = by * a.tiles_per_split;
+    unsigned t_end = t + a.tiles_per_split;
+    if (t_end > a.total_tiles) t_end = a.total_tiles;
+    TileWalk w;
+    w.seek(t, a.tiles_per_chunk);
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < t_end) nxt = load_source<D>(a, w, tid);
+    for (; t < t_end; ++t) {
+        tile[tid] = nxt;
+        __syncthreads();
+        if (t + 1 < t_end) {
+            w.next(a.tiles_per_chunk);
+            nxt = load_source<D>(a, w, tid);
+        }
+        f2 ox[PAIRS], oy[PAIRS], oz[PAIRS];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) ox[q] = oy[q] = oz[q] = f2{0.f, 0.f};
+#pragma unroll 1
+        for (int blk = 0; blk < kTile / LB; ++blk) {
+            f2 ax[PAIRS], ay[PAIRS], az[PAIRS];
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
+            const float4* __restrict__ cur = tile + blk * LB;
+#pragma unroll UNROLL
+            for (int j = 0; j < LB; ++j) {
+                const float4 s = cur[j];
+                interact2_staged<D, PAIRS, 0, 0, 1>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
+            }
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; if (D == 3) oz[q] += az[q]; }
+            if (QS) {
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) {
+                    qq[q] = __builtin_elementwise_fma(ax[q], ax[q], qq[q]);
+                    qq[q] = __builtin_elementwise_fma(ay[q], ay[q], qq[q]);
+                    if (D == 3) qq[q] = __builtin_elementwise_fma(az[q], az[q], qq[q]);
+                }
+            }
+        }
+        // level 3: the tile's sums into the lane's own fp64 slots
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            double2 v = sums[(q * D + 0) * 256 + tid];
+            v.x += (double)ox[q].x; v.y += (double)ox[q].y;
+            sums[(q * D + 0) * 256 + tid] = v;
+            v = sums[(q * D + 1) * 256 + tid];
+            v.x += (double)oy[q].x; v.y += (double)oy[q].y;
+            sums[(q * D + 1) * 256 + tid] = v;
+            if (D == 3) {
+                v = sums[(q * D + 2) * 256 + tid];
+                v.x += (double)oz[q].x; v.y += (double)oz[q].y;
+                sums[(q * D + 2) * 256 + tid] = v;
+            }
+        }
+        __syncthreads();   // everybody has read this tile before the next one overwrites it
+    }
+
+    float* __restrict__ hi = a.acc + (size_t)(2u * by) * D * a.pad;
+    float* __restrict__ lo = hi + (size_t)D * a.pad;
+    float* __restrict__ qout = QS ? a.qsum + (size_t)by * a.pad : nullptr;
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const double2 vx = sums[(q * D + 0) * 256 + tid], vy = sums[(q * D + 1) * 256 + tid];
+        const double2 vz = (D == 3) ? sums[(q * D + (D == 3 ? 2 : 0)) * 256 + tid] : double2{0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned i = tgt0 + (2 * q + h) * 256u;
+            if (!a.bad_flag[i]) {  // flagged targets belong to close_set_path + scatter_close_kernel
+                store_hi_lo(a, hi, lo, i, h ? vx.y : vx.x);
+                store_hi_lo(a, hi, lo, (size_t)a.pad + i, h ? vy.y : vy.x);
+                if (D == 3) store_hi_lo(a, hi, lo, 2 * (size_t)a.pad + i, h ? vz.y : vz.x);
+                if (QS) { const float v = h ? qq[q].y : qq[q].x; qout[i] = a.accumulate ? qout[i] + v : v; }
+            } else if (QS) {
+                qout[i] = __builtin_inff();   // a close-set target of this pass keeps no spread sum: it is always a suspect
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Close set (nbx_internal.h).  classify_close_kernel lists the shard's candidate targets (a coordinate
 // below kCloseCoord; once per position update), classify_sources_kernel the candidate sources of the pass
 // being launched (over ALL of the pass's chunks, so pairs that straddle a shard boundary are seen), and
@@ -672,7 +799,7 @@ __global__ __launch_bounds__(256) void scatter_close_kernel(KArgs a) {
         const unsigned i = a.bad_list[slot];
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
-            for (int y = 0; y < a.splits; ++y) v += (double)a.close_acc[((size_t)y * D + k) * a.pad + slot];
+            for (int y = 0; y < a.grid_slices; ++y) v += (double)a.close_acc[((size_t)y * D + k) * a.pad + slot];   // one per grid slice
             float* __restrict__ dst = a.acc + (size_t)k * a.pad + i;
             if (a.accumulate) {
                 *dst = (float)((double)*dst + v);
@@ -706,7 +833,7 @@ __device__ __forceinline__ void plane_sums(const KArgs& a, unsigned i, double (&
         n2 += t * t;
     }
     Q = 0.0;
-    for (int s = 0; s < a.splits; ++s) Q += (double)a.qsum[(size_t)s * a.pad + i];
+    for (int s = 0; s < a.grid_slices; ++s) Q += (double)a.qsum[(size_t)s * a.pad + i];   // one spread sum per grid slice
 }
 
 template <int D>
@@ -834,8 +961,16 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, 0, 2>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, 0, 2>, \
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, 1, 0
 
+// three-level summation: no cap on the tiles per slice (the slice sums are fp64), two planes per slice (hi, lo), no softened builds
+#define NBX_FAST3L(PAIRS, WAVES, UNROLL, LB) \
+    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 0>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 0>, 1, 0, 0, \
+    nullptr, nullptr, nullptr, nullptr, \
+    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 1>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 1>, 2, 0
+
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
+    {"fastpk3l_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 64)},   // + three-level summation (64-source blocks, tile, fp64 slice sums in LDS)
+    {"fastpk3l32_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 32)}, // the same with 32-source blocks
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
     {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},

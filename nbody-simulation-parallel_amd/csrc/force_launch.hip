@@ -77,6 +77,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.chunk_skip = L.chunk_skip;
     a.accumulate = L.accumulate;
     a.splits = L.splits;
+    a.grid_slices = (int)slices;
     a.qsum = L.qsum;
     a.strict_list = nullptr; a.strict_acc = nullptr; a.strict_cap = 0; a.strict_slices = 0; a.strict_budget = 0; a.refine_c2 = 0.0;
     a.cand_list = L.cand_list;
@@ -159,7 +160,7 @@ namespace {
 hipError_t refine_args(int dim, const RefineLaunch& R, KArgs& a) {
     const AccelLaunch& L = R.base;
     if ((dim != 2 && dim != 3) || L.pad == 0 || L.pad % kPadQuantum != 0 || L.splits < 1 || L.n_chunks < 1 || L.count > L.pad ||
-        !L.acc || !L.qsum || !L.counters || !L.bad_flag || R.grid_slices != L.splits)
+        !L.acc || !L.qsum || !L.counters || !L.bad_flag || R.grid_slices < 1 || L.splits % R.grid_slices != 0)
         return hipErrorInvalidValue;
     a = KArgs{};
     a.pos_all = L.pos_all; a.mass_all = L.mass_all; a.acc = L.acc; a.pad = L.pad; a.count = L.count;
@@ -167,6 +168,7 @@ hipError_t refine_args(int dim, const RefineLaunch& R, KArgs& a) {
     a.total_tiles = (unsigned)L.n_chunks * a.tiles_per_chunk;
     a.tgt_chunk = L.tgt_chunk; a.chunk_first = 0; a.chunk_skip = INT_MAX; a.accumulate = 0;
     a.splits = L.splits;
+    a.grid_slices = R.grid_slices;
     a.bad_flag = L.bad_flag; a.counters = L.counters; a.qsum = L.qsum;
     a.strict_list = R.strict_list; a.strict_acc = R.strict_acc; a.strict_cap = R.strict_cap; a.strict_slices = R.strict_slices;
     a.strict_budget = R.strict_budget;

@@ -35,10 +35,12 @@
 #include "nbx_ctx.h"
 #include "leaf_plan.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -378,6 +380,40 @@ __global__ __launch_bounds__(256) void leaf_scatter_kernel(const double* __restr
     for (int k = 0; k < dim; ++k) forces[(size_t)body * dim + k] = gm * acc[(size_t)k * pslots + p];
 }
 
+// ---- kernels of the device-resident plan (nbx_leaf_plan_*) ----
+// resident fp32 SoA (a single-shard context's source copy: pos[dim][pad], mass[pad]) -> leaf-ordered source pairs
+__global__ __launch_bounds__(256) void leaf_gather_soa_kernel(const float* __restrict__ pos, const float* __restrict__ mass, unsigned pad, int dim,
+                                                              const uint32_t* __restrict__ pslot_body, uint32_t pslots, float* __restrict__ xp,
+                                                              uint32_t* __restrict__ max_mass_bits) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t body = p < pslots ? pslot_body[p] : 0xffffffffu;
+    float x = kFar, y = kFar, z = dim == 3 ? kFar : 0.0f, m = 0.0f;
+    if (body != 0xffffffffu) {
+        x = pos[body]; y = pos[(size_t)pad + body]; z = dim == 3 ? pos[2 * (size_t)pad + body] : 0.0f; m = mass[body];
+    }
+    uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_fabsf(m));
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)mb, d);
+        mb = other > mb ? other : mb;
+    }
+    if ((threadIdx.x & 63u) == 0u && mb > __atomic_load_n(max_mass_bits, __ATOMIC_RELAXED)) atomicMax(max_mass_bits, mb);
+    if (p >= pslots) return;
+    float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
+    o[0] = x; o[2] = y; o[4] = z; o[6] = m;
+}
+
+// forces[body] = (signedG m_body) * sums[slot of body], one lane per body (every entry written: zero for a body in no leaf);
+// the mass comes from mass[body * mass_stride] -- a context's m64 (stride 1) or the staged Body<D> array (offset 2 dim, stride the body's)
+__global__ __launch_bounds__(256) void leaf_forces_by_body_kernel(const double* __restrict__ sums, uint32_t pslots, const uint32_t* __restrict__ body_slot,
+                                                                  size_t n, int dim, double signedG, const double* __restrict__ mass, size_t mass_stride,
+                                                                  double* __restrict__ forces) {
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= n) return;
+    const uint32_t slot = body_slot[b];
+    const double gm = signedG * mass[b * mass_stride];
+    for (int k = 0; k < dim; ++k) forces[b * dim + k] = slot == 0xffffffffu ? 0.0 : gm * sums[(size_t)k * pslots + slot];
+}
+
 typedef void (*LeafKernel)(LeafArgs);
 LeafKernel pick(int dim, int law, int waves) {
     static const LeafKernel table[2][2][3] = {
@@ -412,7 +448,13 @@ hipError_t take_arena(int device, size_t bytes, char** out, size_t* got) {
         }
     }
     *got = bytes;
-    return hipMalloc((void**)out, bytes);
+    hipError_t e = hipMalloc((void**)out, bytes);
+    if (e == hipErrorOutOfMemory) {   // the cache itself may be what is in the way: give the parked blocks back and try once more
+        (void)hipGetLastError();
+        nbx::release_parked_leaf_arenas();
+        e = hipMalloc((void**)out, bytes);
+    }
+    return e;
 }
 
 void park_arena(int device, char* p, size_t bytes) {   // nothing on the device uses p any more
@@ -479,20 +521,12 @@ void release_parked_leaf_arenas() {
 }
 }  // namespace nbx
 
-extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, const uint32_t* leaf_offsets,
-                                    const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
-                                    const uint32_t* list_sources, int law, double G, int device, double* forces_out,
-                                    float* kernel_ms) {
-    if (kernel_ms) *kernel_ms = 0.0f;
-    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
-    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
-    if ((!bodies || !forces_out) && n) return fail(NBX_ERR_INVALID, "null argument");
+namespace {
+// Host-side validation of the CSR structure: every index the kernels will follow is checked here, before anything is launched.
+int validate_csr(size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                 const uint32_t* list_sources, size_t* slots_out) {
     if (n > ((size_t)1 << 31) || n_leaves > ((size_t)1 << 31)) return fail(NBX_ERR_INVALID, "too many bodies / leaves");
-    const size_t min_stride = (size_t)(2 * dim + 1) * sizeof(double);
-    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
-        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
     if (n_leaves && (!leaf_offsets || !list_offsets)) return fail(NBX_ERR_INVALID, "null leaf arrays");
-    // ---- host-side validation of the CSR structure: every index the kernel will follow is checked here ----
     const size_t slots = n_leaves ? leaf_offsets[n_leaves] : 0;
     const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
     if (n_leaves && (leaf_offsets[0] != 0 || list_offsets[0] != 0)) return fail(NBX_ERR_INVALID, "CSR offsets must start at 0");
@@ -510,6 +544,31 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     }
     for (size_t e = 0; e < n_list; ++e)
         if (list_sources[e] >= n_leaves) return fail(NBX_ERR_INVALID, "list_sources entry out of range");
+    *slots_out = slots;
+    return NBX_OK;
+}
+
+// The caller's current HIP device is put back when an entry point of this file returns
+struct DeviceScope {
+    int before = -1;
+    DeviceScope() { if (hipGetDevice(&before) != hipSuccess) before = -1; (void)hipGetLastError(); }
+    ~DeviceScope() { if (before >= 0) (void)hipSetDevice(before); }
+};
+}  // namespace
+
+extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t stride_bytes, const uint32_t* leaf_offsets,
+                                    const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                                    const uint32_t* list_sources, int law, double G, int device, double* forces_out,
+                                    float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if ((!bodies || !forces_out) && n) return fail(NBX_ERR_INVALID, "null argument");
+    const size_t min_stride = (size_t)(2 * dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    size_t slots = 0;
+    if (int vrc = validate_csr(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots)) return vrc;
     int ndev = 0;
     int rc = nbx_device_count(&ndev);
     if (rc != NBX_OK) return rc;
@@ -519,6 +578,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
         return NBX_OK;
     }
 
+    DeviceScope scope;   // the caller's current device is restored on every path
     NBX_HIP_TRY(hipSetDevice(device));
     DeviceBuffers d;
     d.device = device;
@@ -581,18 +641,9 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipGetLastError());
     LeafArgs a;
     a.xp = xp; a.pslots = (uint32_t)pslots; a.ops = d_ops; a.blocks = d_blocks; a.acc = acc; a.max_mass_bits = d_max_mass;
-    // NBX_LEAF_TIMING_REPS=R (a measurement aid, 2 <= R <= 1000): the pair kernel is launched R times back to back -- it writes the
-    // same sums every time -- and kernel_ms reports the mean of the second half of the launches: the kernel's duration once the
-    // clocks have come up from idle (2.3 GHz after ~30 ms of load), as they are inside a running tree code.  The single launch of
-    // an ordinary call follows the call's host work and copies and runs at ~2.05 GHz.
-    int reps = 1;
-    if (const char* e = getenv("NBX_LEAF_TIMING_REPS")) { reps = atoi(e); if (reps < 1) reps = 1; if (reps > 1000) reps = 1000; }
-    const int timed_from = reps / 2;
-    for (int r = 0; r < reps; ++r) {
-        if (r == timed_from) NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-        hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
-        NBX_HIP_TRY(hipGetLastError());
-    }
+    NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
+    hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
+    NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
     hipLaunchKernelGGL(leaf_scatter_kernel, dim3(gs), dim3(256), 0, d.stream, acc, raw, stride_bytes / sizeof(double), dim, d_pb, (uint32_t)pslots,
@@ -600,9 +651,285 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     NBX_HIP_TRY(hipGetLastError());
     NBX_HIP_TRY(hipMemcpyAsync(forces_out, dforces, n * (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, d.stream));
     NBX_HIP_TRY(hipStreamSynchronize(d.stream));
-    if (kernel_ms) {
-        NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, d.ev0, d.ev1));
-        *kernel_ms /= (float)(reps - timed_from);
-    }
+    if (kernel_ms) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, d.ev0, d.ev1));
     return NBX_OK;
 }
+
+// ---- device-resident plan (include/nbody_hip.h "device-resident leaf plan") ---------------------------------------------------
+// What a tree code keeps between force evaluations while its tree stands: the validated structure laid out for the kernel
+// (leaf_plan.h) and every device buffer an evaluation needs.  An evaluation is then: gather (16 B per slot from the resident
+// fp32 source copy), pair kernel, and -- only if the caller wants them on the host -- forces by body and one copy out.
+struct nbx_leaf_plan {
+    int device = 0, dim = 3, waves = 2;
+    size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0;
+    char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass
+    float4* xp = nullptr;
+    double* sums = nullptr;         // [dim][pslots]
+    uint32_t* pslot_body = nullptr; // [pslots]
+    uint32_t* body_slot = nullptr;  // [n]  inverse map, 0xffffffff for a body in no leaf
+    CopyOp* ops = nullptr;
+    LeafBlock* blocks = nullptr;
+    uint32_t* max_mass = nullptr;
+    double* forces = nullptr;       // [n][dim], allocated when a caller first asks for forces on the host
+    double* raw = nullptr;          // staged Body<D> array of nbx_leaf_plan_forces, allocated on first use
+    size_t raw_bytes = 0;
+    hipStream_t stream = nullptr;   // own stream (host-bodies path)
+    hipStream_t last_stream = nullptr;   // stream the last evaluation was ordered on
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+    bool evaluated = false;
+    int last_law = NBX_LAW_TREE_LEAF;
+    double last_signedG = 0.0;
+    // masses of the last evaluation: a context's m64 (stride 1) or the staged bodies (offset 2 dim, stride the body's)
+    const double* last_mass = nullptr;
+    size_t last_mass_stride = 1;
+};
+
+namespace {
+
+int plan_set_device(const nbx_leaf_plan* p) {
+    (void)hipGetLastError();
+    NBX_HIP_TRY(hipSetDevice(p->device));
+    return NBX_OK;
+}
+
+// Work about to be queued on `s` must see the plan's buffers as the last evaluation (possibly on another stream) left them.
+int plan_order_after_last(nbx_leaf_plan* p, hipStream_t s) {
+    if (p->last_stream && p->last_stream != s) NBX_HIP_TRY(hipStreamWaitEvent(s, p->done, 0));
+    return NBX_OK;
+}
+
+int plan_mark_done(nbx_leaf_plan* p, hipStream_t s) {
+    NBX_HIP_TRY(hipEventRecord(p->done, s));
+    p->last_stream = s;
+    return NBX_OK;
+}
+
+int plan_launch_pairs(nbx_leaf_plan* p, int law, hipStream_t s, bool timed) {
+    if (p->n_blocks == 0) return NBX_OK;
+    LeafArgs a;
+    a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
+    if (timed) NBX_HIP_TRY(hipEventRecord(p->ev0, s));
+    hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
+    NBX_HIP_TRY(hipGetLastError());
+    if (timed) NBX_HIP_TRY(hipEventRecord(p->ev1, s));
+    return NBX_OK;
+}
+
+int plan_forces_out(nbx_leaf_plan* p, hipStream_t s, double* forces_out) {
+    if (!p->forces && p->n) NBX_HIP_TRY(hipMalloc((void**)&p->forces, p->n * (size_t)p->dim * sizeof(double)));
+    if (p->n) {
+        hipLaunchKernelGGL(leaf_forces_by_body_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, s, p->sums, (uint32_t)p->pslots,
+                           p->body_slot, p->n, p->dim, p->last_signedG, p->last_mass, p->last_mass_stride, p->forces);
+        NBX_HIP_TRY(hipGetLastError());
+        NBX_HIP_TRY(hipMemcpyAsync(forces_out, p->forces, p->n * (size_t)p->dim * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    NBX_HIP_TRY(hipStreamSynchronize(s));
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies,
+                         size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources) {
+    if (!out) return fail(NBX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
+    size_t slots = 0;
+    if (int vrc = validate_csr(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots)) return vrc;
+    int ndev = 0;
+    int rc = nbx_device_count(&ndev);
+    if (rc != NBX_OK) return rc;
+    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
+    LeafPlan host;
+    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host)) return fail(NBX_ERR_INVALID, why);
+    nbx_leaf_plan* p = new (std::nothrow) nbx_leaf_plan();
+    if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
+    p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;
+    p->pslots = host.pslots(); p->n_ops = host.ops.size(); p->n_blocks = host.blocks.size();
+    std::vector<uint32_t> body_slot;
+    try { body_slot.assign(n, 0xffffffffu); } catch (...) { delete p; return fail(NBX_ERR_ALLOC, "host allocation failed"); }
+    for (size_t s = 0; s < p->pslots; ++s)
+        if (host.pslot_body[s] != 0xffffffffu) body_slot[host.pslot_body[s]] = (uint32_t)s;
+    DeviceScope scope;
+#define PLAN_TRY(expr)                                                                                             \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) { const int r_ = nbx::fail_hip(e_, #expr, __FILE__, __LINE__); nbx_leaf_plan_destroy(p); return r_; } \
+    } while (0)
+    PLAN_TRY(hipSetDevice(device));
+    PLAN_TRY(nbx::take_stream(device, &p->stream));
+    PLAN_TRY(hipEventCreate(&p->ev0));
+    PLAN_TRY(hipEventCreate(&p->ev1));
+    PLAN_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    const size_t sizes[7] = {p->pslots * sizeof(float4), (size_t)dim * p->pslots * sizeof(double), p->pslots * sizeof(uint32_t),
+                             n * sizeof(uint32_t), p->n_ops * sizeof(CopyOp), p->n_blocks * sizeof(LeafBlock), sizeof(uint32_t)};
+    size_t offs[7], total = 0;
+    for (int i = 0; i < 7; ++i) { offs[i] = total; total += (sizes[i] + 255) / 256 * 256 + 256; }
+    PLAN_TRY(hipMalloc((void**)&p->arena, total));
+    p->xp = reinterpret_cast<float4*>(p->arena + offs[0]);
+    p->sums = reinterpret_cast<double*>(p->arena + offs[1]);
+    p->pslot_body = reinterpret_cast<uint32_t*>(p->arena + offs[2]);
+    p->body_slot = reinterpret_cast<uint32_t*>(p->arena + offs[3]);
+    p->ops = reinterpret_cast<CopyOp*>(p->arena + offs[4]);
+    p->blocks = reinterpret_cast<LeafBlock*>(p->arena + offs[5]);
+    p->max_mass = reinterpret_cast<uint32_t*>(p->arena + offs[6]);
+    if (p->pslots) PLAN_TRY(hipMemcpyAsync(p->pslot_body, host.pslot_body.data(), sizes[2], hipMemcpyHostToDevice, p->stream));
+    if (n) PLAN_TRY(hipMemcpyAsync(p->body_slot, body_slot.data(), sizes[3], hipMemcpyHostToDevice, p->stream));
+    if (p->n_ops) PLAN_TRY(hipMemcpyAsync(p->ops, host.ops.data(), sizes[4], hipMemcpyHostToDevice, p->stream));
+    if (p->n_blocks) PLAN_TRY(hipMemcpyAsync(p->blocks, host.blocks.data(), sizes[5], hipMemcpyHostToDevice, p->stream));
+    PLAN_TRY(hipMemsetAsync(p->sums, 0, sizes[1] ? sizes[1] : 8, p->stream));   // slots no workgroup writes (a leaf's pad) stay zero
+    PLAN_TRY(hipStreamSynchronize(p->stream));   // the host arrays above go out of scope
+#undef PLAN_TRY
+    *out = p;
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_destroy(nbx_leaf_plan* p) {
+    if (!p) return NBX_OK;
+    DeviceScope scope;
+    (void)hipSetDevice(p->device);
+    if (p->last_stream) (void)hipStreamSynchronize(p->last_stream);
+    bool idle = p->stream && hipStreamSynchronize(p->stream) == hipSuccess;
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->forces) (void)hipFree(p->forces);
+    if (p->raw) (void)hipFree(p->raw);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->done) (void)hipEventDestroy(p->done);
+    if (p->stream) { if (idle) nbx::park_stream(p->device, p->stream); else (void)hipStreamDestroy(p->stream); }
+    (void)hipGetLastError();
+    delete p;
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_info(const nbx_leaf_plan* p, size_t* slots, size_t* runs, size_t* workgroups, int* waves) {
+    if (!p) return fail(NBX_ERR_INVALID, "plan is null");
+    if (slots) *slots = p->pslots;
+    if (runs) *runs = p->n_ops;
+    if (workgroups) *workgroups = p->n_blocks;
+    if (waves) *waves = p->waves;
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_forces(nbx_leaf_plan* p, const void* bodies, size_t stride_bytes, int law, double G, double* forces_out, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (!p) return fail(NBX_ERR_INVALID, "plan is null");
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if ((!bodies || !forces_out) && p->n) return fail(NBX_ERR_INVALID, "null argument");
+    const size_t min_stride = (size_t)(2 * p->dim + 1) * sizeof(double);
+    if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
+        return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    hipStream_t s = p->stream;
+    if ((rc = plan_order_after_last(p, s))) return rc;
+    const size_t bytes = p->n * stride_bytes;
+    if (bytes > p->raw_bytes) {
+        if (p->raw) { NBX_HIP_TRY(hipStreamSynchronize(s)); NBX_HIP_TRY(hipFree(p->raw)); p->raw = nullptr; p->raw_bytes = 0; }
+        NBX_HIP_TRY(hipMalloc((void**)&p->raw, bytes + 256));
+        p->raw_bytes = bytes;
+    }
+    if (bytes) NBX_HIP_TRY(hipMemcpyAsync(p->raw, bodies, bytes, hipMemcpyHostToDevice, s));
+    NBX_HIP_TRY(hipMemsetAsync(p->max_mass, 0, sizeof(uint32_t), s));
+    if (p->pslots) {
+        hipLaunchKernelGGL(leaf_gather_kernel, dim3((unsigned)((p->pslots + 255) / 256)), dim3(256), 0, s, p->raw, stride_bytes / sizeof(double), p->dim,
+                           p->pslot_body, (uint32_t)p->pslots, reinterpret_cast<float*>(p->xp), p->max_mass);
+        NBX_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = plan_launch_pairs(p, law, s, true))) return rc;
+    p->evaluated = true; p->last_law = law;
+    p->last_signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
+    p->last_mass = p->raw + 2 * p->dim; p->last_mass_stride = stride_bytes / sizeof(double);
+    if ((rc = plan_mark_done(p, s))) return rc;
+    if ((rc = plan_forces_out(p, s, forces_out))) return rc;
+    if (kernel_ms && p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, double* forces_out, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (!p || !c) return fail(NBX_ERR_INVALID, "null argument");
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if (c->device != p->device || c->dim != p->dim || c->n_total != p->n || c->n_shards != 1)
+        return fail(NBX_ERR_INVALID, "the context must be a single-shard context of the plan's device, dimension and body count");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies to the context first");
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = plan_order_after_last(p, s))) return rc;
+    NBX_HIP_TRY(hipMemsetAsync(p->max_mass, 0, sizeof(uint32_t), s));
+    if (p->pslots) {
+        hipLaunchKernelGGL(leaf_gather_soa_kernel, dim3((unsigned)((p->pslots + 255) / 256)), dim3(256), 0, s, c->pos_all, c->mass_all, c->pad, p->dim,
+                           p->pslot_body, (uint32_t)p->pslots, reinterpret_cast<float*>(p->xp), p->max_mass);
+        NBX_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = plan_launch_pairs(p, law, s, kernel_ms != nullptr))) return rc;
+    p->evaluated = true; p->last_law = law;
+    p->last_signedG = (law == NBX_LAW_BRUTE) ? -G : G;
+    p->last_mass = c->m64; p->last_mass_stride = 1;
+    if ((rc = plan_mark_done(p, s))) return rc;
+    if (forces_out) { if ((rc = plan_forces_out(p, s, forces_out))) return rc; }
+    else if (kernel_ms) NBX_HIP_TRY(hipStreamSynchronize(s));
+    if (kernel_ms && p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_get_forces(nbx_leaf_plan* p, double* forces_out) {
+    if (!p || (!forces_out && p->n)) return fail(NBX_ERR_INVALID, "null argument");
+    if (!p->evaluated) return fail(NBX_ERR_STATE, "no evaluation on the device");
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    return plan_forces_out(p, p->last_stream, forces_out);
+}
+
+int nbx_leaf_plan_kick_drift(nbx_leaf_plan* p, nbx_ctx* c, double dt) {
+    if (!p || !c) return fail(NBX_ERR_INVALID, "null argument");
+    if (!p->evaluated) return fail(NBX_ERR_STATE, "evaluate the leaf sums before kick_drift");
+    if (c->device != p->device || c->dim != p->dim || c->n_total != p->n || c->n_shards != 1)
+        return fail(NBX_ERR_INVALID, "the context must be a single-shard context of the plan's device, dimension and body count");
+    if (p->last_mass != c->m64) return fail(NBX_ERR_STATE, "the last evaluation was not made from this context");
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = plan_order_after_last(p, s))) return rc;
+    SlotKickArgs k;
+    k.sums = p->sums; k.body_slot = p->body_slot; k.pslots = (uint32_t)p->pslots; k.dim = p->dim; k.pad = c->pad; k.count = c->count;
+    k.signedG = p->last_signedG; k.dt = dt; k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64; k.pos_chunk = c->pos_all;
+    NBX_HIP_TRY(launch_kick_drift_slots(k, s));
+    c->have_accel = false;                          // the context's own accelerations (if any) belong to the old positions
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    return plan_mark_done(p, s);
+}
+
+int nbx_leaf_plan_time_kernel(nbx_leaf_plan* p, int law, int reps, float* mean_ms) {
+    if (!p || !mean_ms) return fail(NBX_ERR_INVALID, "null argument");
+    *mean_ms = 0.0f;
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if (reps < 1 || reps > 1000) return fail(NBX_ERR_INVALID, "reps must be in [1, 1000]");
+    if (!p->evaluated) return fail(NBX_ERR_STATE, "evaluate once before timing (the bodies of the last evaluation are used)");
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    hipStream_t s = p->last_stream;
+    const int timed_from = reps / 2;
+    for (int r = 0; r < reps; ++r) {
+        if (r == timed_from) NBX_HIP_TRY(hipEventRecord(p->ev0, s));
+        if ((rc = plan_launch_pairs(p, law, s, false))) return rc;
+    }
+    NBX_HIP_TRY(hipEventRecord(p->ev1, s));
+    NBX_HIP_TRY(hipStreamSynchronize(s));
+    if (p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(mean_ms, p->ev0, p->ev1));
+    *mean_ms /= (float)(reps - timed_from);
+    // the sums now belong to `law`: keep the bookkeeping of the last evaluation consistent with them
+    p->last_signedG = (law == NBX_LAW_BRUTE) ? -std::fabs(p->last_signedG) : std::fabs(p->last_signedG);
+    p->last_law = law;
+    return NBX_OK;
+}
+
+}  // extern "C"

@@ -132,7 +132,13 @@ int dev_alloc(nbx_ctx* c, T** p, size_t bytes) {
         return NBX_OK;
     }
     void* q = nullptr;
-    HIP_TRY(hipMalloc(&q, bytes));
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipErrorOutOfMemory) {   // the leaf path's parked allocations (up to 2 x 2 GiB per device) may be what is in the way
+        (void)hipGetLastError();
+        release_parked_leaf_arenas();
+        e = hipMalloc(&q, bytes);
+    }
+    HIP_TRY(e);
     c->extra.push_back(q);
     *p = static_cast<T*>(q);
     return NBX_OK;
@@ -171,7 +177,8 @@ int ensure_stage(nbx_ctx* c, size_t bytes) {
 int effective_variant(const nbx_ctx* c) {
     int v = c->variant_req >= 0 ? c->variant_req : default_variant();
     if (c->softening > 0.0) {  // softened law: the fast kernels with bias = eps^2; no close set, no guarded twin
-        if (!variant_is_fast(v) || !variant_has_law_builds(v)) v = default_variant();   // A/B table entries carry no soft build
+        if (!variant_is_fast(v) || !variant_has_law_builds(v))   // A/B table entries and the three-level kernel carry no soft build
+            v = variant_has_law_builds(default_variant()) ? default_variant() : default_fast_two_rcp_variant();
         if (variant_needs_extent(v) && !c->extent_ok) v = default_fast_two_rcp_variant();
         return v;
     }
@@ -311,7 +318,7 @@ RefineLaunch refine_launch(const nbx_ctx* c) {
     R.strict_budget = c->strict_budget;
     const double r = (c->refine_sigma > 0.0 ? c->refine_sigma : c->dim == 2 ? kRefineSigmaDefault2D : kRefineSigmaDefault3D) * kUnitRoundoffF32 / c->refine_tol;
     R.c2 = r * r;
-    R.grid_slices = c->splits;
+    R.grid_slices = c->splits / variant_planes(c->variant);
     return R;
 }
 

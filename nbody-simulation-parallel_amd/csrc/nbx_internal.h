@@ -120,7 +120,8 @@ struct KArgs {
     unsigned tiles_per_split;
     int tgt_chunk, chunk_first, chunk_skip;
     int accumulate;
-    int splits;
+    int splits;                // fp32 planes of acc (= grid slices x planes per slice)
+    int grid_slices;           // source slices of the launch = planes of close_acc and of qsum
     unsigned close_blocks;     // fast kernels: workgroups with blockIdx.x < close_blocks run close_set_path
     unsigned* __restrict__ cand_list;
     float* __restrict__ cand_pos;
@@ -234,6 +235,20 @@ struct KickDriftArgs {
     float* pos_chunk;      // this shard's chunk of pos_all: [dim][pad]
 };
 hipError_t launch_kick_drift(const KickDriftArgs& k, hipStream_t stream);
+// The same update from fp64 leaf sums indexed by padded slot (leaf plan, leaf_pair_kernel.hip): body l's sum is
+// sums[k][body_slot[l]] (0 when body_slot[l] == 0xffffffff: the body belongs to no leaf); F = (signedG m) sum.
+struct SlotKickArgs {
+    const double* sums;        // [dim][pslots]
+    const uint32_t* body_slot; // [count]
+    uint32_t pslots;
+    int dim;
+    unsigned pad;
+    size_t count;
+    double signedG, dt;
+    double* x64; double* v64; const double* m64;
+    float* pos_chunk;
+};
+hipError_t launch_kick_drift_slots(const SlotKickArgs& k, hipStream_t stream);
 
 // forces_out: AoS double[count][dim] on the device
 hipError_t launch_export_forces(const float* acc, int splits, int dim, unsigned pad, size_t count,

@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(KickDriftArgs a) {
     a.pos_chunk[(size_t)k * a.pad + l] = (float)x;
 }
 
+// The leaf plan's stepping loop: the same two helpers fed the near-field sums of the tree codes (fp64, per padded slot).
+__global__ __launch_bounds__(256) void kick_drift_slots_kernel(SlotKickArgs a) {
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= a.count) return;
+    const int k = (int)blockIdx.y;
+    const double m = a.m64[l];
+    const uint32_t slot = a.body_slot[l];
+    const double sum = slot == 0xffffffffu ? 0.0 : a.sums[(size_t)k * a.pslots + slot];
+    const double F = (a.signedG * m) * sum;
+    double v = a.v64[(size_t)k * a.pad + l];
+    double x = a.x64[(size_t)k * a.pad + l];
+    v += (F / m) * a.dt;
+    x += v * a.dt;
+    a.v64[(size_t)k * a.pad + l] = v;
+    a.x64[(size_t)k * a.pad + l] = x;
+    a.pos_chunk[(size_t)k * a.pad + l] = (float)x;
+}
+
 __global__ __launch_bounds__(256) void export_forces_kernel(const float* __restrict__ acc, int splits, int dim,
                                                             unsigned pad, size_t count, double G,
                                                             const double* __restrict__ m64,
@@ -202,6 +220,12 @@ hipError_t launch_pack(const PackArgs& p, hipStream_t stream) {
 hipError_t launch_kick_drift(const KickDriftArgs& k, hipStream_t stream) {
     if (k.count == 0) return hipSuccess;
     hipLaunchKernelGGL(kick_drift_kernel, dim3(blocks_for(k.count), (unsigned)k.dim, 1), dim3(256), 0, stream, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_kick_drift_slots(const SlotKickArgs& k, hipStream_t stream) {
+    if (k.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(kick_drift_slots_kernel, dim3(blocks_for(k.count), (unsigned)k.dim, 1), dim3(256), 0, stream, k);
     return hipGetLastError();
 }
 

@@ -37,6 +37,84 @@ std::vector<Vector<D>> leaf_pair_direct_forces_hip(const std::vector<Body<D>>& b
     return forces;
 }
 
+namespace {
+[[noreturn]] void raise_leaf(const char* where, int rc) {
+    std::string msg = std::string(where) + ": " + nbx_strerror(rc);
+    const char* detail = nbx_last_error_detail();
+    if (detail && *detail) msg += std::string(" -- ") + detail;
+    throw std::runtime_error(msg);
+}
+int leaf_device() {
+    if (const char* e = std::getenv("NBODY_HIP_DEVICE")) return std::atoi(e);
+    return 0;
+}
+}  // namespace
+
+template <int D>
+LeafPairSimulationHip<D>::LeafPairSimulationHip(const std::vector<Body<D>>& bodies, const LeafLists& L) : n_(bodies.size()) {
+    if (L.leaf_offsets.empty() || L.list_offsets.size() != L.leaf_offsets.size())
+        throw std::runtime_error("LeafPairSimulationHip: leaf_offsets and list_offsets need n_leaves + 1 entries");
+    const int device = leaf_device();
+    int rc = nbx_leaf_plan_create(&plan_, device, D, n_, L.leaf_offsets.data(), L.leaf_bodies.data(), L.leaves(), L.list_offsets.data(),
+                                  L.list_sources.data());
+    if (!rc) rc = nbx_ctx_create(&ctx_, device, D, n_, 1, 0);
+    if (!rc) rc = nbx_ctx_upload_bodies(ctx_, bodies.data(), sizeof(Body<D>));
+    if (rc != NBX_OK) {
+        nbx_leaf_plan_destroy(plan_);
+        nbx_ctx_destroy(ctx_);
+        plan_ = nullptr; ctx_ = nullptr;
+        raise_leaf("LeafPairSimulationHip", rc);
+    }
+}
+template <int D>
+LeafPairSimulationHip<D>::~LeafPairSimulationHip() {
+    nbx_leaf_plan_destroy(plan_);   // before the context: its last evaluation may still be queued on the context's stream
+    nbx_ctx_destroy(ctx_);
+}
+template <int D>
+std::vector<Vector<D>> LeafPairSimulationHip<D>::forces(LeafLaw law, double G) {
+    std::vector<Vector<D>> f(n_);
+    const int rc = nbx_leaf_plan_forces_ctx(plan_, ctx_, static_cast<int>(law), G, reinterpret_cast<double*>(f.data()), nullptr);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::forces", rc);
+    return f;
+}
+template <int D>
+void LeafPairSimulationHip<D>::evaluate(LeafLaw law, double G) {
+    int rc = nbx_leaf_plan_forces_ctx(plan_, ctx_, static_cast<int>(law), G, nullptr, nullptr);
+    if (!rc) rc = nbx_ctx_synchronize(ctx_);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::evaluate", rc);
+}
+template <int D>
+void LeafPairSimulationHip<D>::step(LeafLaw law, double G, double dt, int nsteps) {
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = nbx_leaf_plan_forces_ctx(plan_, ctx_, static_cast<int>(law), G, nullptr, nullptr);
+        if (!rc) rc = nbx_leaf_plan_kick_drift(plan_, ctx_, dt);
+        if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::step", rc);
+    }
+}
+template <int D>
+void LeafPairSimulationHip<D>::download(std::vector<Body<D>>& bodies) {
+    if (bodies.size() != n_) throw std::runtime_error("LeafPairSimulationHip::download: body count differs");
+    const int rc = nbx_ctx_download_bodies(ctx_, bodies.data(), sizeof(Body<D>));
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::download", rc);
+}
+template <int D>
+float LeafPairSimulationHip<D>::single_launch_ms(LeafLaw law, double G) {
+    float ms = 0.0f;
+    const int rc = nbx_leaf_plan_forces_ctx(plan_, ctx_, static_cast<int>(law), G, nullptr, &ms);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::single_launch_ms", rc);
+    return ms;
+}
+template <int D>
+float LeafPairSimulationHip<D>::back_to_back_ms(LeafLaw law, int reps) {
+    float ms = 0.0f;
+    const int rc = nbx_leaf_plan_time_kernel(plan_, static_cast<int>(law), reps, &ms);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::back_to_back_ms", rc);
+    return ms;
+}
+template class LeafPairSimulationHip<2>;
+template class LeafPairSimulationHip<3>;
+
 template <int D>
 LeafLists build_uniform_leaves(const std::vector<Body<D>>& bodies, int depth) {
     LeafLists L;

@@ -33,6 +33,32 @@ enum class LeafLaw : int {
 template <int D>
 std::vector<Vector<D>> leaf_pair_direct_forces_hip(const std::vector<Body<D>>& bodies, const LeafLists& lists, LeafLaw law);
 
+// The same sums for a tree that STANDS while the bodies move -- the reference's call pattern: bvh.cpp:143-176 evaluates the
+// leaf sums of a built BVH in every force evaluation, fmm_parlay.cpp:916-1022 once per step.  The structure is validated, laid
+// out and uploaded once (nbx_leaf_plan_*), the bodies live on the device (a context), and every evaluation only re-gathers
+// positions and runs the pair kernel.  Every method throws std::runtime_error on failure; no CPU fallback.
+template <int D>
+class LeafPairSimulationHip {
+public:
+    LeafPairSimulationHip(const std::vector<Body<D>>& bodies, const LeafLists& lists);
+    ~LeafPairSimulationHip();
+    LeafPairSimulationHip(const LeafPairSimulationHip&) = delete;
+    LeafPairSimulationHip& operator=(const LeafPairSimulationHip&) = delete;
+    // leaf sums of the bodies as they stand on the device, brought to the host
+    std::vector<Vector<D>> forces(LeafLaw law, double G);
+    // the same evaluation with the sums left on the device; returns after the device has finished (wall-clock friendly)
+    void evaluate(LeafLaw law, double G);
+    // nsteps x { leaf sums; update_body_velocities; update_body_positions } (methods.cpp:425-450) on the device, asynchronous
+    void step(LeafLaw law, double G, double dt, int nsteps);
+    void download(std::vector<Body<D>>& bodies);
+    float single_launch_ms(LeafLaw law, double G);      // pair kernel of one evaluation
+    float back_to_back_ms(LeafLaw law, int reps);      // measurement: mean of the second half of `reps` launches in a row
+private:
+    struct nbx_ctx* ctx_ = nullptr;
+    struct nbx_leaf_plan* plan_ = nullptr;
+    std::size_t n_ = 0;
+};
+
 // Fixed-depth subdivision of the bodies' bounding box (2^depth cells per axis, box padded like fmm.cpp:386-387):
 // non-empty cells are the leaves, each leaf's list is itself followed by its non-empty adjacent cells -- the simplest
 // tree that produces the reference's neighbour-list structure (fmm.cpp:455-476).

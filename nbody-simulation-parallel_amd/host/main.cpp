@@ -12,11 +12,13 @@
 // The tree methods (b, h, f) are outside this build's scope: accepted on the command line, reported
 // as "not built", skipped.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
 #include <iomanip>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -271,11 +273,61 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                     pairs += static_cast<double>(lists.leaf_offsets[t + 1] - lists.leaf_offsets[t]) *
                              static_cast<double>(lists.leaf_offsets[lists.list_sources[e] + 1] - lists.leaf_offsets[lists.list_sources[e]]);
             const double kernel_ms = last_leaf_pair_kernel_ms();
-            out << "Time taken: " << seconds << " s  (" << lists.leaves() << " leaves, " << pairs << " pair terms, kernel "
-                << kernel_ms << " ms = " << pairs / (kernel_ms * 1e-3) << " pair terms/s, "
-                << 100.0 * pairs * 20.0 / (kernel_ms * 1e-3) / 157.3e12 << " % of MI355X fp32 peak at 20 flop/pair"
-                << (std::getenv("NBX_LEAF_TIMING_REPS") ? "; NBX_LEAF_TIMING_REPS: mean of the second half of that many launches" : "; one launch")
-                << ")" << std::endl;
+            auto rate = [&](double ms) {
+                std::ostringstream o;
+                o << ms << " ms = " << pairs / (ms * 1e-3) << " pair terms/s, " << 100.0 * pairs * 20.0 / (ms * 1e-3) / 157.3e12
+                  << " % of MI355X fp32 peak at 20 flop/pair";
+                return o.str();
+            };
+            out << "Time taken: " << seconds << " s  (one-shot call: validation, layout, copies, kernels; " << lists.leaves() << " leaves, " << pairs
+                << " pair terms, kernel " << rate(kernel_ms) << "; one launch)" << std::endl;
+            // The same sums the way a tree code asks for them: the structure made resident once (nbx_leaf_plan_*), the bodies on the
+            // device, every evaluation = gather + pair kernel (bvh.cpp:143-176 / fmm_parlay.cpp:916-1022 evaluate a standing tree)
+            try {
+                const auto t0 = std::chrono::steady_clock::now();
+                LeafPairSimulationHip<D> sim(bodies, lists);
+                const auto t1 = std::chrono::steady_clock::now();
+                const Forces planned = sim.forces(LeafLaw::FmmP2P, ::G);
+                bool same = planned.size() == forces.size();
+                for (std::size_t i = 0; same && i < planned.size(); ++i)
+                    for (int k = 0; k < D; ++k) same = same && planned[i][k] == forces[i][k];
+                double best = 1e30;
+                for (int r = 0; r < 10; ++r) {
+                    const auto a = std::chrono::steady_clock::now();
+                    sim.evaluate(LeafLaw::FmmP2P, ::G);
+                    best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
+                }
+                const float single = sim.single_launch_ms(LeafLaw::FmmP2P, ::G);
+                const float warm = sim.back_to_back_ms(LeafLaw::FmmP2P, 300);
+                out << "Resident plan: created in " << std::chrono::duration<double, std::milli>(t1 - t0).count()
+                    << " ms; an evaluation of the unchanged structure from resident bodies takes " << best << " ms wall (best of 10); forces "
+                    << (same ? "equal the one-shot call's bit for bit" : "DIFFER from the one-shot call's") << std::endl
+                    << "  pair kernel, single launch: " << rate(single) << std::endl
+                    << "  pair kernel, mean of launches 151-300 back to back (clocks up): " << rate(warm) << std::endl;
+                if (!same) g_exit_code = 3;
+                csv << "NearField_HIP_plan," << n << "," << D;
+                write_time(csv, best * 1e-3);
+                if (opt.accuracy) csv << ",";
+                csv << std::endl;
+                if (opt.steps > 0) {
+                    // a tree code whose far field is zero: k steps of {leaf sums; kick; drift} with the structure standing
+                    std::vector<Body<D>> state = bodies;
+                    const auto s0 = std::chrono::steady_clock::now();
+                    sim.step(LeafLaw::FmmP2P, opt.G, opt.dt, opt.steps);
+                    sim.download(state);
+                    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s0).count();
+                    out << "Near-field stepping on HIP: " << opt.steps << " steps of {leaf sums, kick, drift} in " << ms << " ms (" << ms / opt.steps
+                        << " ms/step), dt = " << opt.dt << ", G = " << opt.G << std::endl;
+                    csv << "NearField_HIP_" << opt.steps << "steps," << n << "," << D;
+                    write_time(csv, ms * 1e-3);
+                    if (opt.accuracy) csv << ",";
+                    csv << std::endl;
+                    if (!opt.dump.empty()) dump_raw(opt.dump + "_NearField_steps.f64", state);
+                }
+            } catch (const std::exception& e) {
+                out << "Resident plan: unavailable (" << e.what() << ")" << std::endl;
+                g_exit_code = 3;
+            }
             print_validation_forces<D>(forces, n, log);
             print_validation_forces<D>(forces, n, std::cout);
             if (!opt.dump.empty()) dump_raw(opt.dump + "_NearField_HIP.f64", forces);

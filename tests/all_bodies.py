@@ -54,8 +54,10 @@ def error_stats(f, ref, S, tol=1.0e-5):
     return out, rel, back, kappa
 
 
-def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0.0, rows=1100, seed=7, dump=None):
-    """Returns a dict of everything measured; raises AssertionError only for the strict-vs-oracle pin."""
+def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0.0, rows=1100, seed=7, dump=None, variant=None,
+           sigmas=(12.0, 24.0, 32.0, 40.0, 48.0, 64.0, 96.0)):
+    """Returns a dict of everything measured; raises AssertionError only for the strict-vs-oracle pin.
+    variant: name of the fast kernel variant to survey (None: the library default)."""
     G = oracle.G if G is None else G
     n, dim = bodies.shape[0], (bodies.shape[1] - 1) // 2
     m = bodies[:, -1]
@@ -83,7 +85,7 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
         rec["strict_kernel_ms"] = c.kernel_time()[0]
         assert np.array_equal(c.forces(G), fs), "the magnitude-sum build must not change the forces"
         # 2. the default fp32 path, ALL bodies against the strict result
-        c.set_tuning(0, -1)
+        c.set_tuning(0, -1 if variant is None else _variant(nbx, variant))
         rec["default_variant"] = c.effective_tuning()[0]
         rec["default_ms"] = _timed(c, 3)
         rec["default_kernel_ms"] = c.kernel_time()[0]
@@ -91,7 +93,10 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
         rec["default"], rel_f, back_f, kappa = error_stats(ff, fs, S, refine_tol)
         # 3. mixed mode, ALL bodies against the strict result
         c.set_refine(refine_tol, sigma_factor)
+        assert c.effective_tuning()[0] == rec["default_variant"]
         rec["mixed_ms"] = _timed(c, 3)
+        rec["mixed_kernel_ms"] = c.kernel_time()[0]
+        rec["mixed_refine_ms"] = c.refine_time() / 3
         fm = c.forces(G)
         Q = c.aux()
         sel, done = c.refine_stats()
@@ -109,7 +114,7 @@ def survey(nbx, oracle, bodies, label, G=None, refine_tol=1.0e-5, sigma_factor=0
     over = rel_f > 0.5 * refine_tol
     rec["sigma_needed"]["max_among_rel_gt_half_tol"] = float(need[over].max()) if over.any() else None
     rec["sigma_needed"]["n_rel_gt_half_tol"] = int(over.sum())
-    for sf in (12.0, 24.0, 32.0, 40.0, 48.0, 64.0, 96.0):
+    for sf in sigmas:
         flagged = spread * u * sf > refine_tol
         rec[f"rule_sigma_{sf:g}"] = dict(flagged=int(flagged.sum()), missed_over_tol=int((~flagged & (rel_f > refine_tol)).sum()),
                                          worst_unflagged_rel=float(rel_f[~flagged].max()) if (~flagged).any() else 0.0)

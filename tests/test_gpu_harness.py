@@ -152,8 +152,11 @@ def test_near_field_row_through_the_cpp_wrapper(tmp_path, oracle):
     """`-m p`: leaf_pair_direct_forces_hip<3> (host/leaf_pairs_hip.cpp -> nbx_leaf_pair_forces) on the leaves built by the
     C++ side, against the oracle's restatement of fmm_parlay.cpp:992-1020 on the same leaf lists."""
     n = 50000
-    p = _run(tmp_path, "-N", str(n), "-m", "p", "--seed", "9", "--dump", "d")
+    p = _run(tmp_path, "-N", str(n), "-m", "p", "--seed", "9", "--dump", "d", "--steps", "3", "--dt", "2", "--G", "4.471e3")
     assert p.returncode == 0 and "Error executing" not in p.stderr, p.stderr
+    # the resident plan (LeafPairSimulationHip<3> -> nbx_leaf_plan_*): same bits as the one-shot call, and k steps of
+    # {leaf sums, kick, drift} with the structure standing, against the oracle's helpers fed the oracle's leaf sums
+    assert "forces equal the one-shot call's bit for bit" in p.stdout and "Near-field stepping on HIP: 3 steps" in p.stdout, p.stdout[-2000:]
     bodies = np.fromfile(os.path.join(tmp_path, "d_bodies.f64")).reshape(n, 7)
     leaves = tuple(np.fromfile(os.path.join(tmp_path, f"d_{k}.u32"), dtype=np.uint32)
                    for k in ("leaf_offsets", "leaf_bodies", "list_offsets", "list_sources"))
@@ -161,7 +164,19 @@ def test_near_field_row_through_the_cpp_wrapper(tmp_path, oracle):
     br = oracle.round_inputs_to_f32(bodies)
     assert_force_parity(f, oracle.leaf_pair_forces(br, leaves, 2), oracle.leaf_pair_magnitude_sums(br, leaves, 2), "near-field harness row")
     csv = glob.glob(os.path.join(tmp_path, "results", f"run_*_N_{n}_3D.csv"))[0]
-    assert any(l.startswith(f"NearField_HIP,{n},3,") for l in open(csv).read().splitlines())
+    rows = open(csv).read().splitlines()
+    for label in ("NearField_HIP", "NearField_HIP_plan", "NearField_HIP_3steps"):
+        assert any(l.startswith(f"{label},{n},3,") for l in rows), (label, rows)
+    state = np.fromfile(os.path.join(tmp_path, "d_NearField_steps.f64")).reshape(n, 7)
+    ref, scale = bodies.copy(), 4.471e3 / oracle.G
+    for _ in range(3):
+        fr = oracle.leaf_pair_forces(oracle.round_inputs_to_f32(ref), leaves, 2) * scale
+        oracle.update_body_velocities(ref, np.ascontiguousarray(fr), 2.0)
+        oracle.update_body_positions(ref, 2.0)
+    dv = np.linalg.norm(ref[:, 3:6] - bodies[:, 3:6], axis=1)
+    assert dv.max() > 1e-3, "coupling too weak to test anything"
+    assert np.allclose(state[:, 3:6], ref[:, 3:6], rtol=0, atol=2e-5 * dv.max())
+    assert np.allclose(state[:, :3], ref[:, :3], rtol=1e-12, atol=3 * 2.0 * 2e-5 * dv.max())
 
 
 def test_newton_law_through_the_harness(tmp_path):
@@ -208,7 +223,8 @@ def test_every_body_of_the_harness_row_at_n1048576(tmp_path, nbx, oracle):
         fs = c.forces(oracle.G)
     br = oracle.round_inputs_to_f32(bodies)
     rows = np.unique(np.random.default_rng(5).integers(0, n, 1100))
-    ref = oracle.force_rows_omp_2(br, rows)
+    # the device rounds positions and source masses to fp32 (= br) and applies G m_i in fp64 with the caller's own m_i
+    ref = oracle.force_rows_omp_2(br, rows) * (bodies[rows, -1] / br[rows, -1])[:, None]
     d = np.sqrt(((fs[rows] - ref) ** 2).sum(axis=1)) / np.sqrt((ref ** 2).sum(axis=1))
     assert d.max() <= 1e-9, f"strict kernel vs oracle rows: {d.max():.3e}"
     rel = np.sqrt(((f - fs) ** 2).sum(axis=1)) / np.sqrt((fs ** 2).sum(axis=1))

@@ -12,8 +12,25 @@ pytestmark = pytest.mark.gpu
 LAWS = ((0, "brute"), (1, "tree_leaf"), (2, "fmm_p2p"))
 
 
+def _all_paths(nbx, b, leaves, law, G, what=""):
+    """The three ways into the pair kernel give the same bits: the one-shot call (nbx_leaf_pair_forces: validates, lays out and
+    uploads per call), the resident PLAN fed host bodies (nbx_leaf_plan_forces), and the plan fed bodies that live in a context
+    (nbx_leaf_plan_forces_ctx) -- twice, the second time with the sums left on the device (nbx_leaf_plan_get_forces)."""
+    f = nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=G)
+    n, dim = b.shape[0], (b.shape[1] - 1) // 2
+    with nbx.LeafPlan(n, dim, *leaves) as plan:
+        assert np.array_equal(plan.forces(b, law, G), f), f"{what}: plan (host bodies) differs from the one-shot call"
+        if n:
+            with nbx.Context(n, dim) as c:
+                c.upload(b)
+                assert np.array_equal(plan.forces_ctx(c, law, G), f), f"{what}: plan (resident bodies) differs from the one-shot call"
+                plan.forces_ctx(c, law, G, fetch=False)
+                assert np.array_equal(plan.get_forces(), f), f"{what}: second evaluation of the unchanged structure"
+    return f
+
+
 def _check(nbx, oracle, b, leaves, law, what):
-    f = nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=oracle.G)
+    f = _all_paths(nbx, b, leaves, law, oracle.G, what)
     ref = oracle.leaf_pair_forces(b, leaves, law)
     S = oracle.leaf_pair_magnitude_sums(b, leaves, law)
     assert f.shape == ref.shape and np.isfinite(f).all()
@@ -42,10 +59,10 @@ def test_reference_octree_golden(nbx, oracle, dim):
     g = golden(f"octree_direct_D{dim}_N512.npz")
     b = np.ascontiguousarray(g["bodies_f32"])
     one = (np.array([0, 512]), np.arange(512), np.array([0, 1]), np.array([0]))
-    f = nbx.leaf_pair_forces_hip(b, *one, law=nbx.LAW_TREE_LEAF, G=float(g["G"]))
+    f = _all_paths(nbx, b, one, nbx.LAW_TREE_LEAF, float(g["G"]), "octree golden")
     assert_force_parity(f, g["forces_octree_theta0"], oracle.leaf_pair_magnitude_sums(b, one, 1), f"octree golden D={dim}")
     assert np.allclose(f[10], g["forces_octree_theta0"][10], rtol=1e-4, atol=0)      # partner at r^2 = 3.6e-10: skipped
-    fb = nbx.leaf_pair_forces_hip(b, *one, law=nbx.LAW_BRUTE, G=float(g["G"]))
+    fb = _all_paths(nbx, b, one, nbx.LAW_BRUTE, float(g["G"]), "octree golden, brute law")
     assert_force_parity(fb, g["forces_brute_seq"], oracle.force_magnitude_sums(b), f"brute law over one leaf D={dim}")
     assert np.allclose(fb[10], g["forces_brute_seq"][10], rtol=1e-4, atol=0)         # ... and counted by the brute-force law
 
@@ -65,7 +82,7 @@ def test_reference_bvh_golden(nbx, oracle, dim, n):
     nl = lo.size - 1
     leaves = (lo, lb, np.arange(nl + 1, dtype=np.uint32) * nl, np.tile(np.arange(nl, dtype=np.uint32), nl))
     ref = g["forces_bvh_all_leaves"]
-    f = nbx.leaf_pair_forces_hip(b, *leaves, law=nbx.LAW_TREE_LEAF, G=float(g["G"]))
+    f = _all_paths(nbx, b, leaves, nbx.LAW_TREE_LEAF, float(g["G"]), "reference BVH leaves")
     S = oracle.leaf_pair_magnitude_sums(b, leaves, 1)
     e = assert_force_parity(f, ref, S, f"reference BVH leaves D={dim} N={n}")
     orc = oracle.leaf_pair_forces(b, leaves, 1)
@@ -207,8 +224,23 @@ def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
     for leaves in bad:
         with pytest.raises(nbx.NbxError):
             nbx.leaf_pair_forces_hip(b, *leaves)
+        with pytest.raises(nbx.NbxError):
+            nbx.LeafPlan(10, 3, *leaves)
     with pytest.raises(nbx.NbxError):
         nbx.leaf_pair_forces_hip(b, *ok, law=7)
+    with nbx.LeafPlan(10, 3, *ok) as plan:
+        with pytest.raises(nbx.NbxError):
+            plan.forces(b, law=7)
+        with pytest.raises(nbx.NbxError):
+            plan.get_forces()                                       # nothing evaluated yet
+        with pytest.raises(ValueError):
+            plan.forces(oracle.generate(1, 11, 3))                  # another body count
+        with nbx.Context(11, 3) as c, pytest.raises(nbx.NbxError):
+            c.upload(oracle.generate(1, 11, 3))
+            plan.forces_ctx(c)                                      # a context of another size
+        with nbx.Context(10, 3, n_shards=2, shard=0) as c, pytest.raises(nbx.NbxError):
+            c.upload(b)
+            plan.forces_ctx(c)                                      # a sharded context
     assert nbx.leaf_pair_forces_hip(np.zeros((0, 7)), np.array([0]), np.zeros(0), np.array([0]), np.zeros(0)).shape == (0, 3)
 
 
@@ -222,10 +254,71 @@ def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
     ref = oracle.leaf_pair_forces(b, leaves, 2)
     S = oracle.leaf_pair_magnitude_sums(b, leaves, 2)
     assert_force_parity(f, ref, S, "FMM-like leaves, every body")
+    # the resident plan, the pinned TREE_LEAF law, every body; and what a force evaluation of an unchanged structure costs
+    import time
+    with nbx.LeafPlan(n, dim, *leaves) as plan, nbx.Context(n, dim) as c:
+        c.upload(b)
+        ft = plan.forces_ctx(c, nbx.LAW_TREE_LEAF, oracle.G)
+        assert_force_parity(ft, oracle.leaf_pair_forces(b, leaves, 1), oracle.leaf_pair_magnitude_sums(b, leaves, 1), "plan, tree-leaf law, every body")
+        walls = []
+        for _ in range(20):
+            c.synchronize()
+            t0 = time.perf_counter()
+            plan.forces_ctx(c, nbx.LAW_TREE_LEAF, oracle.G, fetch=False)
+            c.synchronize()
+            walls.append((time.perf_counter() - t0) * 1e3)
+        assert np.array_equal(plan.get_forces(), ft)
+        one = plan.forces_ctx(c, nbx.LAW_TREE_LEAF, oracle.G, fetch=False, timed=True)
+        warm = plan.time_kernel(nbx.LAW_TREE_LEAF, 300)
+        print(f"\nplan: evaluation of the unchanged structure from resident bodies: wall median {np.median(walls):.3f} ms (min {min(walls):.3f}), "
+              f"pair kernel {one:.3f} ms single launch, {warm:.3f} ms mean of launches 151-300; slots/runs/workgroups/waves {plan.info()}")
+        assert np.median(walls) <= 0.6, f"second call on an unchanged structure took {np.median(walls):.3f} ms (one-shot call: 3.2 ms)"
     lo, _, so, ss = leaves
     sizes = np.diff(lo).astype(np.int64)
     pairs = int(sum(sizes[t] * sizes[ss[so[t]:so[t + 1]]].sum() for t in range(sizes.size)))
     print(f"\nleaf-pair kernel: N={n}, {sizes.size} leaves (max {sizes.max()}), {pairs:.3e} pair terms in {ms:.2f} ms = {pairs / ms * 1e3:.3e} pairs/s")
+
+
+def test_plan_stepping_matches_the_reference_helpers(nbx, oracle):
+    """nbx_leaf_plan_kick_drift: update_body_velocities + update_body_positions (methods.cpp:425-450) fed the leaf sums of a
+    standing structure, k steps on the device, against the same loop on the host built from the oracle's leaf sums on the
+    fp32-representable positions the device sees.  Strong coupling (G x 1e24) so that the forces bend the paths; bodies in no
+    leaf only drift.  Per-body bound from the stated force tolerance, as in test_config2_trajectory_with_coupling."""
+    n, dim, steps, dt, scale = 8000, 3, 4, 1.5, 1e24
+    b0 = oracle.round_inputs_to_f32(oracle.generate(150, n, dim))
+    lo, lb, so, ss = nbx.leaves.uniform_grid_leaves(b0, dim, 2)
+    keep = lo[-1] - 37                                             # the last 37 slots' bodies end up in no leaf
+    lo = np.minimum(lo, keep)
+    leaves = (lo, lb[:keep], so, ss)
+    G = oracle.G * scale
+    ref = b0.copy()
+    S0 = oracle.leaf_pair_magnitude_sums(b0, leaves, 1) * scale
+    for _ in range(steps):
+        f = oracle.leaf_pair_forces(oracle.round_inputs_to_f32(ref), leaves, 1) * scale
+        oracle.update_body_velocities(ref, np.ascontiguousarray(f), dt)
+        oracle.update_body_positions(ref, dt)
+    got = b0.copy()
+    with nbx.LeafPlan(n, dim, *leaves) as plan, nbx.Context(n, dim) as c:
+        c.upload(b0)
+        for _ in range(steps):
+            plan.forces_ctx(c, nbx.LAW_TREE_LEAF, G, fetch=False)
+            plan.kick_drift(c, dt)
+        c.download(got)
+        # the context's own fp32 source copy followed the drift: a brute-force evaluation sees the new positions
+        c.compute_accel()
+        fb = c.forces(G)
+    dv = np.linalg.norm(ref[:, dim:2 * dim] - b0[:, dim:2 * dim], axis=1)
+    assert np.median(dv) > 1e-4 and dv.max() > 1.0, "coupling too weak to test anything"
+    err = np.linalg.norm(got[:, dim:2 * dim] - ref[:, dim:2 * dim], axis=1)
+    bound = 1.25 * steps * 4.0e-6 * S0 / b0[:, -1] * dt
+    out = np.setdiff1d(np.arange(n), lb[:keep])
+    assert out.size == 37 and np.array_equal(got[out, dim:2 * dim], b0[out, dim:2 * dim]), "bodies in no leaf keep their velocity"
+    live = S0 > 0
+    assert (err[live] <= bound[live]).all(), f"velocity error {float((err[live] / bound[live]).max()):.2f} x the per-body bound"
+    assert np.allclose(got[:, :dim], ref[:, :dim], rtol=1e-9, atol=steps * dt * float(bound.max()))
+    assert np.array_equal(got[:, -1], b0[:, -1])
+    cur = oracle.round_inputs_to_f32(got)
+    assert_force_parity(fb, oracle.brute_force_seq(cur) * scale, oracle.force_magnitude_sums(cur) * scale, "brute force after the plan's drifts")
 
 
 def test_calls_reuse_the_parked_device_allocation(nbx, oracle):

@@ -1,5 +1,5 @@
 """Near-field (leaf-pair) direct sums at FMM-like sizes: N bodies in a uniform grid of leaves (2^(3*level) cells), every
-leaf against its 27-cell neighbourhood, through nbx_leaf_pair_forces; prints the kernel's own time per law.
+leaf against its 27-cell neighbourhood, through nbx_leaf_pair_forces (one-shot) and nbx_leaf_plan_* (resident); prints the kernel's own time per law.
     python tools/time_leaf_pairs.py [N] [level] [box]
 box (default: the reference generator's 1e7) rescales the positions: in a box below 2^14 = 16,384 every target lies inside the
 close set (csrc/nbx_internal.h) and every wave takes the kernel's guarded pair loop."""
@@ -19,20 +19,15 @@ sizes = np.diff(lo).astype(np.int64)
 src = np.add.reduceat(sizes[ss], so[:-1])          # bodies on each leaf's list (every list here is non-empty)
 pairs = int((sizes * src).sum())
 print(f"N={n}, {sizes.size} leaves (mean {sizes.mean():.1f}, max {sizes.max()}), {pairs:.3e} pair terms", flush=True)
-def timed(law, reps):
-    """Best kernel time and best whole-call time of three calls; reps > 1: the library launches the kernel that many times back to
-    back and reports the mean of the second half (NBX_LEAF_TIMING_REPS, csrc/leaf_pair_kernel.hip)."""
-    if reps > 1:
-        os.environ["NBX_LEAF_TIMING_REPS"] = str(reps)
-    else:
-        os.environ.pop("NBX_LEAF_TIMING_REPS", None)
+def timed(law):
+    """Best kernel time and best whole-call time of three ONE-SHOT calls (nbx_leaf_pair_forces: validation, layout, H2D, gather,
+    kernel, scatter, D2H per call)."""
     best, wall = 1e30, 1e30
     for _ in range(3):
         t0 = time.perf_counter()
         _, ms = nbx.leaf_pair_forces_hip(b, *leaves, law=law, return_kernel_ms=True)
         wall = min(wall, (time.perf_counter() - t0) * 1e3)
         best = min(best, ms)
-    os.environ.pop("NBX_LEAF_TIMING_REPS", None)
     return best, wall
 
 
@@ -42,10 +37,28 @@ def rate(ms):
 
 
 LAWS = ((nbx.LAW_BRUTE, "brute"), (nbx.LAW_TREE_LEAF, "tree_leaf"), (nbx.LAW_FMM_P2P, "fmm_p2p"))
-cold = {name: timed(law, 1) for law, name in LAWS}              # all of these before any sustained load
+cold = {name: timed(law) for law, name in LAWS}              # all of these before any sustained load
 for law, name in LAWS:
-    print(f"law {name:9s}: kernel, one launch after the call's host work and copies (clocks at ~2.05 GHz) {rate(cold[name][0])};  "
+    print(f"law {name:9s}: one-shot call: kernel, one launch after the call's host work and copies (clocks at ~2.05 GHz) {rate(cold[name][0])};  "
           f"whole call (validation, layout, H2D, gather, kernel, scatter, D2H) {cold[name][1]:.2f} ms", flush=True)
+# the resident plan (nbx_leaf_plan_*): the structure validated, laid out and uploaded once, bodies resident in a context
+t0 = time.perf_counter()
+plan = nbx.LeafPlan(n, 3, *leaves)
+ctx = nbx.Context(n, 3)
+ctx.upload(b)
+ctx.synchronize()
+print(f"plan: created in {(time.perf_counter() - t0) * 1e3:.2f} ms (validation, layout, uploads, context); slots/runs/workgroups/waves {plan.info()}", flush=True)
 for law, name in LAWS:
-    warm, _ = timed(law, 300)
-    print(f"law {name:9s}: kernel, mean of launches 151-300 back to back (clocks up, ~2.3 GHz) {rate(warm)}", flush=True)
+    walls = []
+    for _ in range(30):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        plan.forces_ctx(ctx, law, fetch=False)
+        ctx.synchronize()
+        walls.append((time.perf_counter() - t0) * 1e3)
+    one = min(plan.forces_ctx(ctx, law, fetch=False, timed=True) for _ in range(3))
+    print(f"law {name:9s}: plan, evaluation of the unchanged structure from resident bodies: wall median {np.median(walls):.3f} ms "
+          f"(min {min(walls):.3f}); pair kernel, single launch {rate(one)}", flush=True)
+for law, name in LAWS:
+    warm = plan.time_kernel(law, 300)
+    print(f"law {name:9s}: pair kernel, mean of launches 151-300 back to back (nbx_leaf_plan_time_kernel; clocks up, ~2.3 GHz) {rate(warm)}", flush=True)
