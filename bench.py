@@ -201,7 +201,7 @@ def parity_block(system, bodies, G, args, world, rank, dist, refine_tol=1.0e-5):
 
     def evaluate():
         be.synchronize()
-        ctx.upload(initial)          # back to the initial state (the timed steps moved the bodies); every rank, all chunks
+        be.upload(initial, system.group)   # back to the initial state (the timed steps moved the bodies): own shard up, the rest gathered
         system.compute_forces()
         return system.forces(G)
 
@@ -497,6 +497,8 @@ def main():
         result["exchange_transport"] = backend
         result["exchange_check"] = exchange_check
         result["per_rank"] = per_rank
+        result["upload"] = {"bytes_over_this_ranks_host_link": be.upload_bytes, "whole_array_bytes": int(bodies.size * 8),
+                            "how": "own shard host-to-device; other shards' masses by one all-gather, positions by the step's exchange"}
         result["exchange_hidden_behind_local_pass"] = all(bool(r["exchange_hidden"]) for r in per_rank)
     if world > 1:
         dist.barrier()

@@ -210,6 +210,18 @@ int nbx_ctx_gather_layout(const nbx_ctx* ctx, size_t* shard_len, size_t* shard_p
  * shard and the fp64 position/velocity/mass state of this context's own shard. */
 int nbx_ctx_upload_bodies(nbx_ctx* ctx, const void* bodies, size_t body_stride_bytes);
 
+/* The same upload for a sharded context that moves only ITS OWN bodies over the host link (one process per GPU: every rank
+ * uploading the whole array costs G copies of it):
+ *   1. nbx_ctx_upload_shard: shard_bodies = the shard_len-or-fewer bodies this context owns (Body<dim> array); packs the own
+ *      chunk of the exchange buffers and the fp64 state; returns the largest |mass| and |coordinate| of the shard;
+ *   2. the caller fills the OTHER chunks of pos_all / mass_all device to device (one all-gather of each; layout above) and
+ *      combines the two maxima over all ranks;
+ *   3. nbx_ctx_upload_finish with the combined maxima: the fast path's preconditions are decided from them (they are properties
+ *      of all bodies), and -- for small-coordinate systems -- the close-set probe runs against every chunk.
+ * nbx_ctx_upload_bodies = the three steps on the whole array in one call. */
+int nbx_ctx_upload_shard(nbx_ctx* ctx, const void* shard_bodies, size_t body_stride_bytes, double* max_abs_mass, double* max_abs_coord);
+int nbx_ctx_upload_finish(nbx_ctx* ctx, double max_abs_mass_all, double max_abs_coord_all);
+
 /* Accelerations of this shard's targets: a_i = sum_j m_j (p_j - p_i)/r^4 over the selected sources
  * (the reference force without the -(G m_i) factor).  which: 0 = all shards' sources,
  * 1 = only this shard's own chunk (needs no remote data), 2 = every other shard's chunk, added to
@@ -377,6 +389,13 @@ int nbx_node_synchronize(nbx_node* node);
 int nbx_node_download_bodies(nbx_node* node, void* bodies, size_t body_stride_bytes);
 int nbx_node_energy(nbx_node* node, double G, double* kinetic, double* potential);
 int nbx_node_kernel_time(nbx_node* node, float* mean_ms, int* launches);
+/* Self-description of a sharded evaluation (what a first run on a multi-GPU node prints): with timing enabled every evaluation
+ * records events around each rank's LOCAL and REMOTE pass (compute stream) and around its part of the exchange (comm stream);
+ * nbx_node_pass_times reports the LAST evaluation's figures for `rank` -- device, targets, the three durations in ms, and whether
+ * the exchange had finished before the LOCAL pass did (exchange_hidden).  Any out pointer may be NULL.  Synchronises. */
+int nbx_node_enable_timing(nbx_node* node, int on);
+int nbx_node_pass_times(nbx_node* node, int rank, int* device, size_t* targets, float* local_ms, float* remote_ms,
+                        float* exchange_ms, int* exchange_hidden);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

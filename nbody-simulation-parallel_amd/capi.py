@@ -55,6 +55,8 @@ ABI = [
     ("nbx_ctx_set_gather_buffers", _i, [_vp, _vp, _vp]),
     ("nbx_ctx_gather_layout", _i, [_vp, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_vp), _c.POINTER(_vp)]),
     ("nbx_ctx_upload_bodies", _i, [_vp, _vp, _sz]),
+    ("nbx_ctx_upload_shard", _i, [_vp, _vp, _sz, _pd, _pd]),
+    ("nbx_ctx_upload_finish", _i, [_vp, _d, _d]),
     ("nbx_ctx_compute_accel", _i, [_vp, _i]),
     ("nbx_ctx_kick_drift", _i, [_vp, _d, _d]),
     ("nbx_ctx_kick_drift2", _i, [_vp, _d, _d, _d]),
@@ -96,6 +98,8 @@ ABI = [
     ("nbx_node_download_bodies", _i, [_vp, _vp, _sz]),
     ("nbx_node_energy", _i, [_vp, _d, _pd, _pd]),
     ("nbx_node_kernel_time", _i, [_vp, _pf, _pi]),
+    ("nbx_node_enable_timing", _i, [_vp, _i]),
+    ("nbx_node_pass_times", _i, [_vp, _i, _pi, _c.POINTER(_sz), _pf, _pf, _pf, _pi]),
 ]
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1, 2
 
@@ -414,6 +418,20 @@ class Context:
             raise ValueError("bodies shape does not match the context")
         self._ck(self.lib.nbx_ctx_upload_bodies(self.h, b.ctypes.data, b.shape[1] * 8), "nbx_ctx_upload_bodies")
 
+    def upload_shard(self, shard_bodies: np.ndarray) -> Tuple[float, float]:
+        """Step 1 of the sharded upload (nbx_ctx_upload_shard): this context's own bodies only; returns (max |mass|, max |coordinate|)
+        of the shard.  The caller then fills the other chunks of the exchange buffers and calls upload_finish."""
+        b, dim = _as_bodies(shard_bodies)
+        if dim != self.dim or b.shape[0] != self.count:
+            raise ValueError("shard_bodies must hold exactly this shard's bodies")
+        m, x = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._ck(self.lib.nbx_ctx_upload_shard(self.h, b.ctypes.data if self.count else None, b.shape[1] * 8, ctypes.byref(m), ctypes.byref(x)),
+                 "nbx_ctx_upload_shard")
+        return m.value, x.value
+
+    def upload_finish(self, max_abs_mass_all: float, max_abs_coord_all: float):
+        self._ck(self.lib.nbx_ctx_upload_finish(self.h, float(max_abs_mass_all), float(max_abs_coord_all)), "nbx_ctx_upload_finish")
+
     def compute_accel(self, which: int = SRC_ALL):
         self._ck(self.lib.nbx_ctx_compute_accel(self.h, which), "nbx_ctx_compute_accel")
 
@@ -536,6 +554,18 @@ class Node:
 
     def set_refine(self, rel_tolerance: float, sigma_factor: float = 0.0):
         self._ck(self.lib.nbx_node_set_refine(self.h, float(rel_tolerance), float(sigma_factor)), "nbx_node_set_refine")
+
+    def enable_timing(self, on: bool = True):
+        self._ck(self.lib.nbx_node_enable_timing(self.h, 1 if on else 0), "nbx_node_enable_timing")
+
+    def pass_times(self, rank: int) -> dict:
+        """Per-rank figures of the last timed evaluation (nbx_node_pass_times)."""
+        dev, tg = ctypes.c_int(0), ctypes.c_size_t(0)
+        l, r, x, h = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+        self._ck(self.lib.nbx_node_pass_times(self.h, rank, ctypes.byref(dev), ctypes.byref(tg), ctypes.byref(l), ctypes.byref(r),
+                                              ctypes.byref(x), ctypes.byref(h)), "nbx_node_pass_times")
+        return {"rank": rank, "device": dev.value, "targets": tg.value, "local_ms": l.value, "remote_ms": r.value,
+                "exchange_ms": x.value, "exchange_hidden": bool(h.value)}
 
     def refine_stats(self) -> Tuple[int, int]:
         """(selected, refined) of the last mixed-mode evaluation, summed over the ranks."""

@@ -536,27 +536,35 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 // is SINGLE-buffered here (two barriers per tile instead of one; the three workgroups of a CU cover each other's waits).
 // QS = 1: Q_i = sum over the LEVEL-1 blocks of |block sum|^2 (the running sums whose roundings dominate), one plane per slice.
 // -------------------------------------------------------------------------------------------------
-template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS>
+// REGSUMS = 1: the fp64 slice sums stay in registers instead (48 more VGPRs: two waves per SIMD -- the two-level kernel loses
+// 0.4 % at that occupancy, profiles/r2/variants_shape.txt); with WAVES = 2 the source tile is double-buffered again (one barrier
+// per tile), with WAVES = 3 the 52 KB of LDS per workgroup leave room for a single tile buffer only (two barriers per tile).
+template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS, int REGSUMS>
 __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
+    constexpr int NBUF = WAVES <= 2 ? 2 : 1;
     static_assert(kTile % LB == 0 && LB % UNROLL == 0, "level-1 blocks tile the source tile");
-    constexpr unsigned kSumBytes = (unsigned)PAIRS * D * 256u * sizeof(double2);   // [PAIRS*D][256] double2 = the two targets of a pair
-    static_assert(2 * kTile * sizeof(float4) <= kSumBytes, "the close-set path's double-buffered tile aliases the slice sums");
-    __shared__ __attribute__((aligned(16))) char smem[kTile * sizeof(float4) + kSumBytes];
+    static_assert(!(REGSUMS && WAVES > 2), "register-resident slice sums need the register budget of two waves per SIMD");
+    constexpr unsigned kTileBytes = 2u * kTile * sizeof(float4);   // room for the close-set path's two buffers in every build
+    constexpr unsigned kSumBytes = REGSUMS ? 0u : (unsigned)PAIRS * D * 256u * sizeof(double2);   // [PAIRS*D][256] double2 = the two targets of a pair
+    constexpr unsigned kOwnTileBytes = (unsigned)NBUF * kTile * sizeof(float4);
+    constexpr unsigned kSmemBytes = (kOwnTileBytes + kSumBytes) > kTileBytes ? (kOwnTileBytes + kSumBytes) : kTileBytes;
+    __shared__ __attribute__((aligned(16))) char smem[kSmemBytes];
     unsigned bx = blockIdx.x, by = blockIdx.y;
     xcd_tile(bx, by);
     if (bx < a.close_blocks) {   // the launch's extra workgroups: guarded evaluation of the close set (they keep no slice sums)
-        close_set_path<D>(a, *reinterpret_cast<float4 (*)[2][kTile]>(smem + kTile * sizeof(float4)), bx, by);
+        close_set_path<D>(a, *reinterpret_cast<float4 (*)[2][kTile]>(smem), bx, by);
         return;
     }
     float4* __restrict__ tile = reinterpret_cast<float4*>(smem);
-    double2* __restrict__ sums = reinterpret_cast<double2*>(smem + kTile * sizeof(float4));
+    double2* __restrict__ sums = reinterpret_cast<double2*>(smem + kOwnTileBytes);
     const f2 bias = f2{kTiny, kTiny};
     const unsigned tid = threadIdx.x;
     const unsigned tgt0 = (bx - a.close_blocks) * (256u * TPL) + tid;
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
 
     f2 ix[PAIRS], iy[PAIRS], iz[PAIRS], qq[QS ? PAIRS : 1];
+    double2 rx[REGSUMS ? PAIRS : 1], ry[REGSUMS ? PAIRS : 1], rz[REGSUMS ? PAIRS : 1];
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
         const unsigned i0 = tgt0 + (2 * q) * 256u, i1 = i0 + 256u;
@@ -564,9 +572,12 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
         iy[q] = f2{tp[(size_t)a.pad + i0], tp[(size_t)a.pad + i1]};
         iz[q] = (D == 3) ? f2{tp[2 * (size_t)a.pad + i0], tp[2 * (size_t)a.pad + i1]} : f2{0.f, 0.f};
         if (QS) qq[q] = f2{0.f, 0.f};
+        if (REGSUMS) rx[q] = ry[q] = rz[q] = double2{0.0, 0.0};
     }
+    if (!REGSUMS) {
 #pragma unroll
-    for (int c = 0; c < PAIRS * D; ++c) sums[c * 256 + tid] = double2{0.0, 0.0};   // own slots only: no barrier needed
+        for (int c = 0; c < PAIRS * D; ++c) sums[c * 256 + tid] = double2{0.0, 0.0};   // own slots only: no barrier needed
+    }
 
     unsigned t = by * a.tiles_per_split;
     unsigned t_end = t + a.tiles_per_split;
@@ -575,8 +586,9 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     w.seek(t, a.tiles_per_chunk);
     float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < t_end) nxt = load_source<D>(a, w, tid);
+    int buf = 0;
     for (; t < t_end; ++t) {
-        tile[tid] = nxt;
+        tile[buf * kTile + tid] = nxt;
         __syncthreads();
         if (t + 1 < t_end) {
             w.next(a.tiles_per_chunk);
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
             f2 ax[PAIRS], ay[PAIRS], az[PAIRS];
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
-            const float4* __restrict__ cur = tile + blk * LB;
+            const float4* __restrict__ cur = tile + buf * kTile + blk * LB;
 #pragma unroll UNROLL
             for (int j = 0; j < LB; ++j) {
                 const float4 s = cur[j];
@@ -610,19 +622,26 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
         // level 3: the tile's sums into the lane's own fp64 slots
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) {
-            double2 v = sums[(q * D + 0) * 256 + tid];
-            v.x += (double)ox[q].x; v.y += (double)ox[q].y;
-            sums[(q * D + 0) * 256 + tid] = v;
-            v = sums[(q * D + 1) * 256 + tid];
-            v.x += (double)oy[q].x; v.y += (double)oy[q].y;
-            sums[(q * D + 1) * 256 + tid] = v;
-            if (D == 3) {
-                v = sums[(q * D + 2) * 256 + tid];
-                v.x += (double)oz[q].x; v.y += (double)oz[q].y;
-                sums[(q * D + 2) * 256 + tid] = v;
+            if (REGSUMS) {
+                rx[q].x += (double)ox[q].x; rx[q].y += (double)ox[q].y;
+                ry[q].x += (double)oy[q].x; ry[q].y += (double)oy[q].y;
+                if (D == 3) { rz[q].x += (double)oz[q].x; rz[q].y += (double)oz[q].y; }
+            } else {
+                double2 v = sums[(q * D + 0) * 256 + tid];
+                v.x += (double)ox[q].x; v.y += (double)ox[q].y;
+                sums[(q * D + 0) * 256 + tid] = v;
+                v = sums[(q * D + 1) * 256 + tid];
+                v.x += (double)oy[q].x; v.y += (double)oy[q].y;
+                sums[(q * D + 1) * 256 + tid] = v;
+                if (D == 3) {
+                    v = sums[(q * D + 2) * 256 + tid];
+                    v.x += (double)oz[q].x; v.y += (double)oz[q].y;
+                    sums[(q * D + 2) * 256 + tid] = v;
+                }
             }
         }
-        __syncthreads();   // everybody has read this tile before the next one overwrites it
+        if (NBUF == 2) buf ^= 1;
+        else __syncthreads();   // single buffer: everybody has read this tile before the next one overwrites it
     }
 
     float* __restrict__ hi = a.acc + (size_t)(2u * by) * D * a.pad;
@@ -630,8 +649,8 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     float* __restrict__ qout = QS ? a.qsum + (size_t)by * a.pad : nullptr;
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
-        const double2 vx = sums[(q * D + 0) * 256 + tid], vy = sums[(q * D + 1) * 256 + tid];
-        const double2 vz = (D == 3) ? sums[(q * D + (D == 3 ? 2 : 0)) * 256 + tid] : double2{0.0, 0.0};
+        const double2 vx = REGSUMS ? rx[q] : sums[(q * D + 0) * 256 + tid], vy = REGSUMS ? ry[q] : sums[(q * D + 1) * 256 + tid];
+        const double2 vz = (D == 3) ? (REGSUMS ? rz[q] : sums[(q * D + (D == 3 ? 2 : 0)) * 256 + tid]) : double2{0.0, 0.0};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned i = tgt0 + (2 * q + h) * 256u;
@@ -962,15 +981,17 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
     accel_fast_pk_kernel<2, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, accel_fast_pk_kernel<3, PAIRS, WAVES, UNROLL, ONE_RCP, 0, 1, 1, 1>, 1, 0
 
 // three-level summation: no cap on the tiles per slice (the slice sums are fp64), two planes per slice (hi, lo), no softened builds
-#define NBX_FAST3L(PAIRS, WAVES, UNROLL, LB) \
-    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 0>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 0>, 1, 0, 0, \
+#define NBX_FAST3L(PAIRS, WAVES, UNROLL, LB, REGSUMS) \
+    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 0, REGSUMS>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 0, REGSUMS>, 1, 0, 0, \
     nullptr, nullptr, nullptr, nullptr, \
-    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 1>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 1>, 2, 0
+    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, 2, 0
 
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
-    {"fastpk3l_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 64)},   // + three-level summation (64-source blocks, tile, fp64 slice sums in LDS)
-    {"fastpk3l32_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 32)}, // the same with 32-source blocks
+    {"fastpk3l_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 64, 0)},   // + three-level summation (64-source blocks, tile, fp64 slice sums in LDS; single tile buffer)
+    {"fastpk3l_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 0)},   // two waves per SIMD: double-buffered tiles, fp64 slice sums in LDS
+    {"fastpk3lr_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 1)},  // two waves per SIMD: double-buffered tiles, fp64 slice sums in registers
+    {"fastpk3lr32_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 32, 1)},// the same with 32-source blocks
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
     {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},

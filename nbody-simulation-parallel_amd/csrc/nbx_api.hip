@@ -367,7 +367,7 @@ namespace nbx {
 // pack pass, and what that pass learnt about the bodies (facts: PackArgs::facts).  With only_own the other chunks of the
 // exchange buffers are NOT filled: the node layer brings them in from the ranks that own them (nbx_node.hip), so that R
 // ranks move the array over the host links once instead of R times.
-int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3]) {
+int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3], bool bodies_is_own_slice) {
     if (!c || (!bodies && c->n_total)) return fail(NBX_ERR_INVALID, "null argument");
     const size_t min_stride = (size_t)(2 * c->dim + 1) * sizeof(double);
     if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
@@ -379,7 +379,7 @@ int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_
         if ((rc = dev_alloc(c, &c->mass_all, (size_t)c->n_shards * c->pad * sizeof(float)))) return rc;
         c->own_gather = true;
     }
-    const size_t first = only_own ? (size_t)c->shard * c->shard_len : 0;
+    const size_t first = (only_own && !bodies_is_own_slice) ? (size_t)c->shard * c->shard_len : 0;   // offset into the caller's array
     const size_t nb = only_own ? c->count : c->n_total;
     const size_t bytes = nb * stride_bytes;
     rc = ensure_stage(c, bytes ? bytes : 8);
@@ -654,6 +654,43 @@ int nbx_ctx_upload_bodies(nbx_ctx* c, const void* bodies, size_t stride_bytes) {
     unsigned long long facts[3] = {0, 0, 0};
     int rc = upload_stage(c, bodies, stride_bytes, /*only_own=*/false, facts);
     if (rc) return rc;
+    return upload_finish(c, facts);
+}
+
+int nbx_ctx_upload_shard(nbx_ctx* c, const void* shard_bodies, size_t stride_bytes, double* max_abs_mass, double* max_abs_coord) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!shard_bodies && c->count) return fail(NBX_ERR_INVALID, "null argument");
+    unsigned long long facts[3] = {0, 0, 0};
+    c->uploaded = false;
+    // a rank whose shard is empty still packs its (all-pad) chunk: massless bodies at the origin
+    static const double dummy[8] = {0};
+    int rc = upload_stage(c, c->count ? shard_bodies : dummy, stride_bytes, /*only_own=*/true, facts, /*bodies_is_own_slice=*/true);
+    if (rc) return rc;
+    std::memcpy(c->pending_facts, facts, sizeof facts);
+    c->shard_staged = true;
+    double m = 0.0, x = 0.0;
+    std::memcpy(&m, &facts[0], sizeof m);
+    std::memcpy(&x, &facts[1], sizeof x);
+    if (max_abs_mass) *max_abs_mass = m;
+    if (max_abs_coord) *max_abs_coord = x;
+    return NBX_OK;
+}
+
+int nbx_ctx_upload_finish(nbx_ctx* c, double max_abs_mass_all, double max_abs_coord_all) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->shard_staged) return fail(NBX_ERR_STATE, "nbx_ctx_upload_shard first");
+    unsigned long long facts[3];
+    std::memcpy(facts, c->pending_facts, sizeof facts);
+    // the fast path's preconditions are properties of ALL bodies: the caller hands in the maxima over every shard (a NaN stays a
+    // NaN through a max that is written as !(a <= b) ? ... -- whatever arrives here fails the comparisons it has to fail)
+    double m = 0.0, x = 0.0;
+    std::memcpy(&m, &facts[0], sizeof m);
+    std::memcpy(&x, &facts[1], sizeof x);
+    if (!(max_abs_mass_all <= m)) m = max_abs_mass_all;
+    if (!(max_abs_coord_all <= x)) x = max_abs_coord_all;
+    std::memcpy(&facts[0], &m, sizeof m);
+    std::memcpy(&facts[1], &x, sizeof x);
+    c->shard_staged = false;
     return upload_finish(c, facts);
 }
 

@@ -15,6 +15,8 @@ struct nbx_ctx {
     bool splits_user = false;
     int user_slices = 0;           // the caller's source_splits (nbx_ctx_set_tuning), a lower bound on the slice count
     bool uploaded = false, have_accel = false;
+    bool shard_staged = false;                 // nbx_ctx_upload_shard done, nbx_ctx_upload_finish pending
+    unsigned long long pending_facts[3] = {0, 0, 0};
     hipStream_t own_stream = nullptr, stream = nullptr;
     // exchange buffers (own or caller's)
     float* pos_all = nullptr;
@@ -108,7 +110,8 @@ void park_stream(int device, hipStream_t s);
 void release_parked_streams();
 // the two halves of nbx_ctx_upload_bodies (nbx_api.hip), apart so that the node layer can upload each rank's own shard
 // only and fill the other chunks device to device in between
-int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3]);
+int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3],
+                 bool bodies_is_own_slice = false);   // true: `bodies` points at this shard's first body, not at body 0
 int upload_finish(nbx_ctx* c, const unsigned long long facts[3]);
 void release_parked_communicators();   // nbx_node.hip
 void release_parked_leaf_arenas();     // leaf_pair_kernel.hip

@@ -76,6 +76,8 @@ struct Rank {
     void* nccl = nullptr;
     float* pos_all = nullptr;
     size_t chunk_floats = 0;
+    // pass timing of the LAST evaluation (nbx_node_enable_timing): LOCAL / REMOTE on the compute stream, the exchange on the comm stream
+    hipEvent_t t_l0 = nullptr, t_l1 = nullptr, t_r0 = nullptr, t_r1 = nullptr, t_x0 = nullptr, t_x1 = nullptr;
 };
 
 }  // namespace
@@ -86,6 +88,8 @@ struct nbx_node {
     std::vector<Rank> ranks;
     Rccl rccl;
     bool uploaded = false;
+    bool timing = false;              // record the per-rank pass events of every evaluation
+    bool timed_once = false;          // ... and at least one evaluation has been recorded
     bool exchange_verified = false;   // the RCCL exchange passed its poisoned-buffer self-check
     bool rccl_failed = false;         // an RCCL call returned an error: the communicators are not reused
 };
@@ -114,6 +118,12 @@ int start_exchange(nbx_node* nd) {
             for (int q = 0; q < R; ++q)
                 if (q != r) NBX_HIP_TRY(hipStreamWaitEvent(k.comm, nd->ranks[q].ready, 0));
     }
+    if (nd->timing)
+        for (int r = 0; r < R; ++r) {
+            Rank& k = nd->ranks[r];
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            NBX_HIP_TRY(hipEventRecord(k.t_x0, k.comm));
+        }
     if (nd->exchange == NBX_EXCHANGE_RCCL) {
         int rc = nd->rccl.GroupStart();
         if (rc) return nccl_fail(nd, rc, "ncclGroupStart");
@@ -141,6 +151,7 @@ int start_exchange(nbx_node* nd) {
         Rank& k = nd->ranks[r];
         NBX_HIP_TRY(hipSetDevice(k.device));
         NBX_HIP_TRY(hipEventRecord(k.exchanged, k.comm));
+        if (nd->timing) NBX_HIP_TRY(hipEventRecord(k.t_x1, k.comm));
     }
     return NBX_OK;
 }
@@ -174,17 +185,23 @@ int mark_ready(nbx_node* nd) {
 int evaluate(nbx_node* nd) {
     int rc = start_exchange(nd);
     if (rc) return rc;
+    const bool timing = nd->timing && nd->n_ranks > 1;
     for (Rank& k : nd->ranks) {
+        if (timing) { NBX_HIP_TRY(hipSetDevice(k.device)); NBX_HIP_TRY(hipEventRecord(k.t_l0, k.ctx->stream)); }
         rc = nbx_ctx_compute_accel(k.ctx, nd->n_ranks == 1 ? NBX_SRC_ALL : NBX_SRC_LOCAL);
         if (rc) return rc;
+        if (timing) NBX_HIP_TRY(hipEventRecord(k.t_l1, k.ctx->stream));
     }
     if (nd->n_ranks == 1) return NBX_OK;
     rc = finish_exchange(nd);
     if (rc) return rc;
     for (Rank& k : nd->ranks) {
+        if (timing) { NBX_HIP_TRY(hipSetDevice(k.device)); NBX_HIP_TRY(hipEventRecord(k.t_r0, k.ctx->stream)); }
         rc = nbx_ctx_compute_accel(k.ctx, NBX_SRC_REMOTE);
         if (rc) return rc;
+        if (timing) NBX_HIP_TRY(hipEventRecord(k.t_r1, k.ctx->stream));
     }
+    if (timing) nd->timed_once = true;
     return NBX_OK;
 }
 
@@ -303,6 +320,8 @@ int nbx_node_destroy(nbx_node* nd) {
         if (k.nccl && nd->rccl.CommDestroy) (void)nd->rccl.CommDestroy(k.nccl);
         if (k.ready) (void)hipEventDestroy(k.ready);
         if (k.exchanged) (void)hipEventDestroy(k.exchanged);
+        for (hipEvent_t e : {k.t_l0, k.t_l1, k.t_r0, k.t_r1, k.t_x0, k.t_x1})
+            if (e) (void)hipEventDestroy(e);
         if (k.comm) {   // synchronised above; parked for the next node / context on this device (nbx_api.hip)
             if (hipStreamQuery(k.comm) == hipSuccess) park_stream(k.device, k.comm);
             else (void)hipStreamDestroy(k.comm);
@@ -455,6 +474,50 @@ int nbx_node_set_refine(nbx_node* nd, double rel_tolerance, double sigma_factor)
         int rc = nbx_ctx_set_refine(k.ctx, rel_tolerance, sigma_factor);
         if (rc) return rc;
     }
+    return NBX_OK;
+}
+
+int nbx_node_enable_timing(nbx_node* nd, int on) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    if (on)
+        for (Rank& k : nd->ranks) {
+            NBX_HIP_TRY(hipSetDevice(k.device));
+            for (hipEvent_t* e : {&k.t_l0, &k.t_l1, &k.t_r0, &k.t_r1, &k.t_x0, &k.t_x1})
+                if (!*e) NBX_HIP_TRY(hipEventCreate(e));
+        }
+    nd->timing = on != 0;
+    nd->timed_once = false;
+    return NBX_OK;
+}
+
+int nbx_node_pass_times(nbx_node* nd, int rank, int* device, size_t* targets, float* local_ms, float* remote_ms, float* exchange_ms,
+                        int* exchange_hidden) {
+    if (!nd) return fail(NBX_ERR_INVALID, "node is null");
+    if (rank < 0 || rank >= nd->n_ranks) return fail(NBX_ERR_INVALID, "rank out of range");
+    Rank& k = nd->ranks[rank];
+    if (device) *device = k.device;
+    if (targets) *targets = k.ctx->count;
+    if (local_ms) *local_ms = 0.f;
+    if (remote_ms) *remote_ms = 0.f;
+    if (exchange_ms) *exchange_ms = 0.f;
+    if (exchange_hidden) *exchange_hidden = 0;
+    if (nd->n_ranks == 1) return NBX_OK;          // one rank: one ALL pass, no exchange (nbx_node_kernel_time has its duration)
+    if (!nd->timed_once) return fail(NBX_ERR_STATE, "no timed evaluation (nbx_node_enable_timing, then compute or step)");
+    int rc = nbx_node_synchronize(nd);
+    if (rc) return rc;
+    NBX_HIP_TRY(hipSetDevice(k.device));
+    float l = 0.f, r = 0.f, x = 0.f, until_x = 0.f;
+    NBX_HIP_TRY(hipEventElapsedTime(&l, k.t_l0, k.t_l1));
+    NBX_HIP_TRY(hipEventElapsedTime(&r, k.t_r0, k.t_r1));
+    NBX_HIP_TRY(hipEventElapsedTime(&x, k.t_x0, k.t_x1));
+    // hidden: this rank's part of the exchange had finished before its LOCAL pass did (two streams of one device: the events'
+    // timestamps compare).  An event of the comm stream that precedes t_l0 yields an error or a negative time: hidden as well.
+    const hipError_t e = hipEventElapsedTime(&until_x, k.t_l0, k.t_x1);
+    (void)hipGetLastError();
+    if (local_ms) *local_ms = l;
+    if (remote_ms) *remote_ms = r;
+    if (exchange_ms) *exchange_ms = x;
+    if (exchange_hidden) *exchange_hidden = (e != hipSuccess || until_x <= l) ? 1 : 0;
     return NBX_OK;
 }
 

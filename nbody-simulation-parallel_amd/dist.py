@@ -10,7 +10,10 @@ per rank:
                     the force kernel over the other ranks' chunks, accumulated on top, then the
                     fused fp64 kick+drift, which rewrites this rank's chunk for the next exchange.
 
-Masses never change, so they are distributed once (every rank uploads the full initial array).
+Masses never change, so they are distributed once, at upload: every rank moves only ITS OWN shard over its host link
+(nbx_ctx_upload_shard), one all-gather brings the other ranks' masses, the step's own exchange the positions, and the
+preconditions of the fast force path (largest mass / coordinate over ALL bodies) are combined with one all-reduce
+(nbx_ctx_upload_finish) -- the protocol of the single-process node layer (csrc/nbx_node.hip).
 The compute back end is an object with the five methods of `HipShardBackend`; the product back end
 calls the HIP library through its C ABI and has no CPU fallback.  tests/ substitutes a numpy double
 to rehearse the orchestration over gloo.
@@ -32,6 +35,8 @@ class HipShardBackend:
 
     def __init__(self, bodies: np.ndarray, layout: ShardLayout, device_index: int, variant: int = -1,
                  source_splits: int = 0, refine_tol: Optional[float] = None):
+        """Buffers, streams and the context; the bodies go to the device in upload() (make_hip_system calls it: a collective
+        for n_shards > 1).  `bodies` is only looked at for its shape here."""
         if not torch.cuda.is_available():
             raise capi.NbxError(capi.NBX_ERR_NO_DEVICE, "HipShardBackend", "no GPU visible to torch; there is no CPU fallback")
         self.layout = layout
@@ -50,7 +55,6 @@ class HipShardBackend:
         if refine_tol is not None:   # None: the library default (mixed mode, 1e-5); 0: plain fp32
             self.ctx.set_refine(refine_tol)   # mixed mode: the suspects of every evaluation re-evaluated in fp64 after the REMOTE pass
         torch.cuda.synchronize(self.device)  # zero fills done before the library's stream writes
-        self.ctx.upload(bodies)
         self._timing = False
         self._marks = []       # per step: dict of torch events (see enable_timing)
         self._cur = None
@@ -58,6 +62,49 @@ class HipShardBackend:
         # torch / RCCL build reject or mishandle the aliasing, verify_exchange switches to a separate send buffer.
         self.inplace_gather = True
         self._send_buf = None
+
+    # -- upload: own shard over the host link, the rest device to device --
+    def upload(self, bodies: np.ndarray, group=None):
+        """COLLECTIVE for n_shards > 1 (every rank calls it with the same full array, or at least with its own rows right):
+        this rank copies rows [lo, hi) to its device, the masses and positions of the other shards arrive through one all-gather
+        each, the maxima that decide the fast path's preconditions through one all-reduce.  upload_bytes: what crossed this
+        rank's host link."""
+        lo, hi = self.layout.bounds()
+        if self.layout.n_shards == 1:
+            self.ctx.upload(bodies)
+            self.upload_bytes = int(bodies.shape[0] * bodies.shape[1] * 8)
+            return
+        mine = np.ascontiguousarray(bodies[lo:hi])
+        m, x = self.ctx.upload_shard(mine)
+        self.upload_bytes = int(mine.size * 8)
+        self.ctx.synchronize()
+        self._gather_chunks_blocking(self.mass_all, group)          # masses: once per upload
+        self.finish_exchange(self.start_exchange(group))            # positions: the exchange every step uses
+        # a NaN must not get lost in a max-reduction whose NaN handling is the transport's business: +inf fails the same tests
+        t = torch.tensor([m if m == m else float("inf"), x if x == x else float("inf")], dtype=torch.float64)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self.compute_stream.synchronize()
+        self.ctx.upload_finish(float(t[0].item()), float(t[1].item()))
+
+    def _gather_chunks_blocking(self, buf: torch.Tensor, group):
+        """All-gather of buf[shard] into buf (chunk-major, every rank's chunk the same size), finished when this returns."""
+        flat = buf.view(self.layout.n_shards, -1)
+        if dist.get_backend(group) != "nccl":      # rehearsal transport: through host memory
+            mine = flat[self.layout.shard].to("cpu")
+            allc = torch.empty((self.layout.n_shards, mine.numel()), dtype=buf.dtype)
+            dist.all_gather_into_tensor(allc.view(-1), mine, group=group)
+            for g in range(self.layout.n_shards):
+                if g != self.layout.shard:
+                    flat[g].copy_(allc[g].to(self.device))
+            torch.cuda.synchronize(self.device)
+            return
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_stream(self.compute_stream)
+            send = flat[self.layout.shard].clone()  # a separate send buffer: nothing to gain from the in-place form once per upload
+            dist.all_gather_into_tensor(flat.view(-1), send, group=group)
+        self.comm_stream.synchronize()
 
     # -- pass timing (bench.py --gpus N): events on the streams the work really runs on --
     def enable_timing(self, on: bool = True):
@@ -344,4 +391,6 @@ def make_hip_system(bodies: np.ndarray, dim: int, rank: int = 0, world_size: int
                     group=None, variant: int = -1, source_splits: int = 0, refine_tol: Optional[float] = None, check_store=None) -> ShardedNBody:
     layout = ShardLayout(n_total=bodies.shape[0], n_shards=world_size, shard=rank, dim=dim)
     be = HipShardBackend(bodies, layout, rank if device_index is None else device_index, variant, source_splits, refine_tol)
-    return ShardedNBody(be, layout, group, check_store)
+    system = ShardedNBody(be, layout, group, check_store)
+    be.upload(bodies, group)     # collective for world_size > 1: own shard over the host link, the rest device to device
+    return system

@@ -229,6 +229,25 @@ void run_benchmark(const std::vector<Body<D>>& bodies, const std::string& run_id
                     } catch (const std::exception& e) {
                         out << "Sharded-vs-single-GPU check: unavailable (" << e.what() << ")" << std::endl;
                     }
+                    // the facts bench.py --gpus N carries in its JSON line (exchange_check, per_rank), from one more evaluation
+                    // outside the timed row: both RCCL paths describe themselves the same way on first contact with a node
+                    try {
+                        const HipNodeReport rep = describe_hip_node<D>(bodies);
+                        out << "exchange_check: transport " << rep.transport << ", mismatching_values " << rep.mismatching_values << " of "
+                            << rep.checked_values_per_rank << " checked per rank" << (rep.mismatching_values ? "  EXCHANGE FAILED" : "  ok") << std::endl;
+                        bool hidden = true;
+                        for (const auto& k : rep.ranks) {
+                            out << "per_rank: rank " << k.rank << " device " << k.device << " targets " << k.targets << std::fixed << std::setprecision(3)
+                                << " local_ms " << k.local_ms << " remote_ms " << k.remote_ms << " exchange_ms " << k.exchange_ms
+                                << " exchange_hidden " << (k.exchange_hidden ? "yes" : "no") << std::setprecision(6) << std::endl;
+                            hidden = hidden && k.exchange_hidden;
+                        }
+                        out << "exchange_hidden_behind_local_pass: " << (hidden ? "yes" : "no") << ";  mixed mode: " << rep.refine_selected
+                            << " listed, " << rep.refine_refined << " re-evaluated over all ranks" << std::endl;
+                        if (rep.mismatching_values) g_exit_code = 3;
+                    } catch (const std::exception& e) {
+                        out << "exchange_check: unavailable (" << e.what() << ")" << std::endl;
+                    }
                 }
                 hipcsv.open(base + "_hip.csv");
                 hipcsv << "Method,Bodies,Dimension,Time(s),KernelTime(s),PairInteractionsPerSec,GPUs,DistinctDevices" << std::endl

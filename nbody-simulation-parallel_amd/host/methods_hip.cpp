@@ -107,6 +107,34 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 }
 
 template <int D>
+HipNodeReport describe_hip_node(const std::vector<Body<D>>& bodies) {
+    HipNodeReport rep;
+    std::vector<int> devs = g_devices.empty() ? std::vector<int>{device_ordinal()} : g_devices;
+    NodeHandle node;
+    int rc = nbx_node_create(&node.h, (int)devs.size(), devs.data(), D, bodies.size(), NBX_EXCHANGE_AUTO);
+    if (!rc) rc = nbx_node_upload_bodies(node.h, bodies.data(), sizeof(Body<D>));
+    int mode = NBX_EXCHANGE_PEER_COPY;
+    if (!rc) rc = nbx_node_exchange_mode(node.h, &mode);
+    rep.transport = devs.size() == 1 ? "none (one rank)" : mode == NBX_EXCHANGE_RCCL ? "rccl" : "peer copies";
+    if (!rc) rc = nbx_node_verify_exchange(node.h, &rep.mismatching_values);
+    if (!rc) rc = nbx_node_enable_timing(node.h, 1);
+    std::vector<Vector<D>> forces(bodies.size());
+    if (!rc) rc = nbx_node_compute_forces(node.h, NBX_REFERENCE_G, reinterpret_cast<double*>(forces.data()));
+    for (int r = 0; r < (int)devs.size() && !rc; ++r) {
+        HipNodeReport::Rank k{};
+        k.rank = r;
+        int hidden = 0;
+        rc = nbx_node_pass_times(node.h, r, &k.device, &k.targets, &k.local_ms, &k.remote_ms, &k.exchange_ms, &hidden);
+        k.exchange_hidden = hidden != 0;
+        rep.ranks.push_back(k);
+    }
+    if (rc != NBX_OK) raise("describe_hip_node", rc);
+    if (!rep.ranks.empty()) rep.checked_values_per_rank = (std::size_t)D * (bodies.size() - rep.ranks[0].targets);
+    if (nbx_node_refine_stats(node.h, &rep.refine_selected, &rep.refine_refined) == NBX_OK) rep.refine_tolerance = hip_refine_tolerance();
+    return rep;
+}
+
+template <int D>
 std::vector<Vector<D>> brute_force_hip_single_gpu(const std::vector<Body<D>>& bodies, int device) {
     std::vector<Vector<D>> forces(bodies.size());
     const int rc = nbx_brute_force_forces(bodies.data(), bodies.size(), D, sizeof(Body<D>), NBX_REFERENCE_G, device,
@@ -203,6 +231,8 @@ template class HipSimulation<3>;
 // explicit instantiations, like nbody-sim-new/methods.cpp:452-499 does for the CPU solvers
 template std::vector<Vector<2>> brute_force_hip_n_body<2>(const std::vector<Body<2>>&);
 template std::vector<Vector<3>> brute_force_hip_n_body<3>(const std::vector<Body<3>>&);
+template HipNodeReport describe_hip_node<2>(const std::vector<Body<2>>&);
+template HipNodeReport describe_hip_node<3>(const std::vector<Body<3>>&);
 template std::vector<Vector<2>> brute_force_hip_single_gpu<2>(const std::vector<Body<2>>&, int);
 template std::vector<Vector<3>> brute_force_hip_single_gpu<3>(const std::vector<Body<3>>&, int);
 template double brute_force_hip_accuracy<2>(const std::vector<Body<2>>&, const std::vector<Vector<2>>&);

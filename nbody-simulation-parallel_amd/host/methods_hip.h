@@ -32,6 +32,21 @@ std::vector<Vector<D>> brute_force_hip_n_body(const std::vector<Body<D>>& bodies
 template <int D>
 std::vector<Vector<D>> brute_force_hip_single_gpu(const std::vector<Body<D>>& bodies, int device);
 
+// Self-description of the sharded path for a first run on a multi-GPU node (the same facts bench.py --gpus N puts in its JSON
+// line): over the devices of set_hip_devices(), one poisoned-buffer exchange check and ONE timed evaluation -- transport,
+// mismatching values, per-rank LOCAL / REMOTE / exchange times, whether the exchange hid behind the LOCAL pass, mixed-mode counts.
+struct HipNodeReport {
+    struct Rank { int rank, device; std::size_t targets; float local_ms, remote_ms, exchange_ms; bool exchange_hidden; };
+    const char* transport = "";          // "rccl" | "peer copies" | "none (one rank)"
+    std::size_t mismatching_values = 0;  // of the exchange self-check (0 = every chunk arrived on every rank)
+    std::size_t checked_values_per_rank = 0;
+    std::vector<Rank> ranks;
+    double refine_tolerance = 0.0;
+    unsigned refine_selected = 0, refine_refined = 0;
+};
+template <int D>
+HipNodeReport describe_hip_node(const std::vector<Body<D>>& bodies);
+
 // nsteps x { forces; update_body_velocities(bodies, forces, dt); update_body_positions(bodies, dt); }
 // (methods.cpp:425-450) with the state resident on the device between steps.
 template <int D>

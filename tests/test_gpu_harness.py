@@ -80,6 +80,12 @@ def test_sharded_rows_through_the_cpp_wrapper(tmp_path, oracle):
     import re
     m = re.search(r"Sharded-vs-single-GPU check \((\d+) sampled rows of BruteForce_HIP_x3 against the 1-GPU row\): max \|dF\|/\|F\| = ([0-9.eE+-]+)\s+ok", p.stdout)
     assert m and int(m.group(1)) == 1024 and float(m.group(2)) < 1e-4, p.stdout[-1500:]
+    # ... and describes itself like bench.py --gpus N does: transport, exchange self-check, per-rank pass times
+    assert re.search(r"exchange_check: transport peer copies, mismatching_values 0 of \d+ checked per rank  ok", p.stdout), p.stdout[-2500:]
+    ranks = re.findall(r"per_rank: rank (\d) device 0 targets (\d+) local_ms ([0-9.]+) remote_ms ([0-9.]+) exchange_ms ([0-9.]+) exchange_hidden (yes|no)", p.stdout)
+    assert [r[0] for r in ranks] == ["0", "1", "2"] and sum(int(r[1]) for r in ranks) == n, ranks
+    assert all(float(r[2]) > 0 and float(r[3]) > 0 for r in ranks), ranks
+    assert "exchange_hidden_behind_local_pass:" in p.stdout and "mixed mode:" in p.stdout
 
 
 def test_dump_and_load_continue_a_run_bit_for_bit(tmp_path):

@@ -108,3 +108,34 @@ def test_parked_streams_and_communicators_are_reused_and_released(nbx, oracle):
     assert_force_parity(f3, oracle.brute_force_seq(b), oracle.force_magnitude_sums(b), "three virtual ranks after a release")
     assert lib.nbx_release_cached() == 0
     assert np.array_equal(nbx.brute_force_hip_n_body(b), first)
+
+
+def test_pass_times_of_a_sharded_evaluation(nbx, oracle):
+    """nbx_node_enable_timing / nbx_node_pass_times: events around every rank's LOCAL and REMOTE pass and its part of the
+    exchange -- what `nbody_sim --gpus G` prints as per_rank lines (the facts bench.py --gpus N carries in its JSON line).
+    Timing must not change a single bit of the forces."""
+    n, dim, ranks = 60000, 3, 4
+    b = oracle.round_inputs_to_f32(oracle.generate(35, n, dim))
+    with nbx.Node(n, dim, [0] * ranks) as node:
+        node.upload(b)
+        f0 = node.forces(oracle.G)
+        with pytest.raises(nbx.NbxError):
+            node.pass_times(0)                      # nothing timed yet
+        node.enable_timing(True)
+        f1 = node.forces(oracle.G)
+        assert np.array_equal(f0, f1)
+        times = [node.pass_times(r) for r in range(ranks)]
+        with pytest.raises(nbx.NbxError):
+            node.pass_times(ranks)
+        node.step(1.0, 2, oracle.G)                 # steps are timed too: the last evaluation's figures replace the first's
+        again = node.pass_times(1)
+    assert [t["rank"] for t in times] == list(range(ranks)) and sum(t["targets"] for t in times) == n
+    for t in times + [again]:
+        assert t["device"] == 0 and t["local_ms"] > 0 and t["remote_ms"] > t["local_ms"] and t["exchange_ms"] >= 0
+        assert isinstance(t["exchange_hidden"], bool)
+    with nbx.Node(5000, dim, [0]) as one:           # one rank: no passes to tell apart, zeros and no error
+        one.upload(b[:5000])
+        one.enable_timing(True)
+        one.forces(oracle.G)
+        t = one.pass_times(0)
+        assert t["targets"] == 5000 and t["local_ms"] == 0 and t["exchange_ms"] == 0

@@ -566,6 +566,49 @@ def test_close_set_mode_follows_the_bodies_during_a_run(nbx, oracle):
     assert max(cand for _, cand, _ in seen) == n                 # the poll at step 16 saw every body in the candidate set
 
 
+def test_graph_replayed_run_through_a_mode_flip_equals_the_eager_loop(nbx, oracle):
+    """The same fly-through (candidate_pairs -> sorted_cells -> candidate_pairs) driven through nbx_ctx_step, whose steps are
+    graph replays in blocks of 16 with the close-set poll in between: ONE call of 56 steps, and seven calls of 8 steps with a
+    synchronisation in between (so that every poll has landed and the next call re-captures the step for the new mode), both
+    bit for bit equal to the eager loop of compute_accel + kick_drift.  The in-call re-capture drains the stream before it
+    destroys the executable graph or reallocates (round 3's ADVICE); whether it triggers inside the one long call depends on
+    the device keeping up with the host -- the results must not."""
+    n, dim, dt, steps = 20000, 3, 1.0, 56
+    rng = np.random.default_rng(9)
+    b = oracle.generate(70, n, dim)
+    p0 = rng.uniform(20000.0, 30000.0, size=(n, dim))
+    target = rng.normal(scale=100.0, size=(n, dim))
+    b[:, :dim] = p0
+    b[:, dim:2 * dim] = (target - p0) / 20.0
+    b = oracle.round_inputs_to_f32(b)
+    G = oracle.G * 1e-12
+    eager, one_call, short_calls = b.copy(), b.copy(), b.copy()
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        for _ in range(steps):
+            c.compute_accel()
+            c.kick_drift(dt, G)
+            c.synchronize()
+        c.download(eager)
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        c.step(dt, steps, G)
+        c.download(one_call)
+        after_one_call = c.close_set_mode()[0]
+    modes = []
+    with nbx.Context(n, dim) as c:
+        c.upload(b)
+        for _ in range(steps // 8):
+            c.step(dt, 8, G)
+            c.synchronize()
+            modes.append(c.close_set_mode()[0])
+        c.download(short_calls)
+    assert np.array_equal(one_call, eager), "one long nbx_ctx_step call differs from the eager loop"
+    assert np.array_equal(short_calls, eager), "short nbx_ctx_step calls differ from the eager loop"
+    assert "sorted_cells" in modes and modes[-1] == "candidate_pairs", modes     # the re-capture between calls really happened
+    assert after_one_call in ("candidate_pairs", "sorted_cells")
+
+
 def test_fuzz_fast_path_against_guarded_kernel(nbx, oracle):
     """Randomised inputs over twelve decades of coordinate scale, offsets, clusters, duplicates, sub-threshold pairs, 1-4
     shards, D = 2 and 3: the default path (fast kernel + whichever close-set mode the library picks) against the oracle,

@@ -1,5 +1,7 @@
 """Interleaved A/B timing of force-kernel variants in one process (guide rule 24).
-   python tools/time_variants.py [N] [rounds] [name-substring ...]"""
+   python tools/time_variants.py [N] [rounds] [name-substring ...]
+NBX_TIME_PLAIN=1 in the environment times the plain fp32 builds (nbx_ctx_set_refine(0)); the default is the library's default
+precision (mixed mode: the builds that also write the spread sums; the time is the force kernel's own, without the fp64 pass)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +15,9 @@ sel = [i for i, nm in enumerate(names) if not pats or any(p in nm for p in pats)
 b = nbx.uniform_bodies(n, 3, 1)
 with nbx.Context(n, 3) as c:
     c.upload(b)
+    if os.environ.get("NBX_TIME_PLAIN"):
+        c.set_refine(0.0)
+    print("precision:", "plain fp32" if os.environ.get("NBX_TIME_PLAIN") else "mixed mode (spread-sum builds)", flush=True)
     res = {v: [] for v in sel}
     for r in range(rounds + 1):
         for v in sel:
