@@ -21,7 +21,8 @@ lib: $(LIB)
 OBJS := $(CSRC)/force_kernel.o $(CSRC)/force_launch.o \
         $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o $(CSRC)/leaf_pair_kernel.o $(CSRC)/close_hash.o
 # name of the force-kernel variant used when the caller does not pick one
-DEFAULT_VARIANT ?= fastpk_t8_w3_u4
+# (round 4: the three-level summation build -- same pair arithmetic, fp32 errors ~3x smaller for +1.5 % time)
+DEFAULT_VARIANT ?= fastpk3l_t8_w3_u4
 # exact (self-contained, guarded) variant used when the fast path's preconditions do not hold
 DEFAULT_EXACT_VARIANT ?= lds_t1_w8_exact_u8
 

@@ -467,7 +467,7 @@ def main():
         # streams by the helper kernels of the same profile, whose byte counts are known exactly (classify_*: 12 B/body,
         # kick_drift: (12 S + 56) B/body read, 60 B/body written: "calibration" in the json, true/reported = 2.00 and 1.00).
         qs = 1 if args.refine else 0   # mixed mode (the default) runs the build that also writes the spread sums
-        kernel_of = {"fastpk_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1, {qs}>", "fastpk1r_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1, {qs}>",
+        kernel_of = {"fastpk3l_t8_w3_u4": f"accel_fast3l_kernel<3, 4, 3, 4, 64, {qs}, 0>", "fastpk_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1, {qs}>", "fastpk1r_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1, {qs}>",
                      "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>", "strict_f64_t4": "accel_f64_kernel<3, 4, 2, 2, 2, 0, 0>"}
         prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
         try:

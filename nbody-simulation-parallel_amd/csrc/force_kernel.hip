@@ -71,7 +71,9 @@ __device__ __forceinline__ void interact(float sx, float sy, float sz, float sm,
 //                 launched only when every |coordinate| <= kOneRcpMaxCoord (nbx_internal.h).
 // NEWTON = 1 (softened Newtonian law, an extension): the weight is m (r^2+eps^2)^-3/2 -- v_rsq_f32 in place of v_rcp_f32
 // and one more v_pk_mul: 14 VALU per two pairs.
-template <int D, int PAIRS, int ONE_RCP, int NEWTON = 0, int HI_SEL = 1>
+// FIRST = 1: the sums START with this source (ax = w d instead of ax += w d): a block's first source, which saves zeroing
+// the 3 PAIRS accumulators per block (the three-level kernel starts a block every 64 sources).
+template <int D, int PAIRS, int ONE_RCP, int NEWTON = 0, int HI_SEL = 1, int FIRST = 0>
 __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f2 szm, const f2 (&ix)[PAIRS],
                                                  const f2 (&iy)[PAIRS], const f2 (&iz)[PAIRS], f2 (&ax)[PAIRS],
                                                  f2 (&ay)[PAIRS], f2 (&az)[PAIRS], const f2 bias) {
@@ -123,6 +125,15 @@ __device__ __forceinline__ void interact2_staged(float sx, float sy, float sz, f
     } else {   // what the compiler makes of it: v_mov_b32 + low-half broadcast (kept for the A/B in profiles/r2)
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) w[q] = f2{szm.y, szm.y} * r2[q];
+    }
+    if (FIRST) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) ax[q] = w[q] * dx[q];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) ay[q] = w[q] * dy[q];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) az[q] = (D == 3) ? w[q] * dz[q] : f2{0.f, 0.f};
+        return;
     }
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) ax[q] = __builtin_elementwise_fma(w[q], dx[q], ax[q]);
@@ -600,11 +611,13 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
 #pragma unroll 1
         for (int blk = 0; blk < kTile / LB; ++blk) {
             f2 ax[PAIRS], ay[PAIRS], az[PAIRS];
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
             const float4* __restrict__ cur = tile + buf * kTile + blk * LB;
+            {   // the block's first source starts the sums (no zeroing)
+                const float4 s = cur[0];
+                interact2_staged<D, PAIRS, 0, 0, 1, 1>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
+            }
 #pragma unroll UNROLL
-            for (int j = 0; j < LB; ++j) {
+            for (int j = 1; j < LB; ++j) {
                 const float4 s = cur[j];
                 interact2_staged<D, PAIRS, 0, 0, 1>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
             }
@@ -989,9 +1002,12 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
     {"fastpk3l_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 64, 0)},   // + three-level summation (64-source blocks, tile, fp64 slice sums in LDS; single tile buffer)
+#ifdef NBX_AB_3L   /* measured and lost, profiles/r4/variants_3l_*.txt: 222.6-225.4 ms against 221.6 */
     {"fastpk3l_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 0)},   // two waves per SIMD: double-buffered tiles, fp64 slice sums in LDS
     {"fastpk3lr_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 1)},  // two waves per SIMD: double-buffered tiles, fp64 slice sums in registers
     {"fastpk3lr32_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 32, 1)},// the same with 32-source blocks
+    {"fastpk3l32_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 32, 0)}, // 32-source blocks: errors another 1.2x smaller, +1.1 % time
+#endif
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL
     {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},

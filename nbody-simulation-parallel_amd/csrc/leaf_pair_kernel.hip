@@ -344,6 +344,105 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
     }
 }
 
+// Packed small leaves (leaf_plan.h PackBlock): one wave64 = K = 64 / w leaves side by side.  The w lanes of a leaf do for it what
+// the two waves above do for theirs -- stage its stream (its own copy runs, its own cursor) into its own region of the tile,
+// then run the pair loop over it with P lanes per target -- and because w, P and the tile size are the block's, every lane of the
+// wave runs the same trip counts: a leaf whose stream has ended, or that has fewer targets than lanes, computes on pad bodies
+// (massless, far away: exact zeros).  No workgroup barrier to speak of (one wave), one start-up per K leaves, every lane
+// group's LDS reads as conflict-free as above.
+struct LeafPackArgs {
+    const float4* __restrict__ xp;
+    uint32_t pslots;
+    const CopyOp* __restrict__ ops;
+    const PackBlock* __restrict__ blocks;
+    const PackSub* __restrict__ subs;
+    double* __restrict__ acc;
+    const uint32_t* __restrict__ max_mass_bits;
+};
+constexpr int kPackPadUnits = 2 * kPadPairs;     // pad units behind a region's tile: the lane groups' last trips reach up to 2 P - 1 pairs past it
+constexpr int kPackTileUnits = 64 * kPackUnitsPerLane;   // K regions x 8 w units = 512 units, whatever w
+constexpr int kPackMaxSubs = 8;                  // w >= 8
+
+template <int D, int LAW>
+__global__ __launch_bounds__(64) void leaf_pack_kernel(LeafPackArgs a) {
+    __shared__ float4 tile[kPackTileUnits + kPackMaxSubs * kPackPadUnits + 16];   // + what the pipelined pair loop reads ahead of its last trip
+    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps], op_base[kPackMaxSubs][kPackMaxOps];
+    __shared__ double osum[3][64];
+    const unsigned lane = threadIdx.x;
+    const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
+    const uint32_t w = bp->w, P = bp->P, n_sub = bp->n_sub, tiles = bp->tiles, sub_lo = bp->sub_lo;   // wave-uniform
+    const unsigned sub = lane / w, lw = lane - sub * w;            // w is 8 or 16
+    const unsigned R = (unsigned)kPackUnitsPerLane * w;            // units of one leaf's tile
+    PackSub my = PackSub{0u, 0u, 0u, 0u};
+    if (sub < n_sub) my = a.subs[sub_lo + sub];
+    const uint32_t W = my.count ? my.count : 1u;
+    // lw / W through fp32, as above ((lw + 0.5) / W is at least 1/32 away from an integer)
+    const unsigned g_raw = (unsigned)(((float)lw + 0.5f) * __builtin_amdgcn_rcpf((float)W));
+    const unsigned t = lw - g_raw * W;
+    const bool valid = my.count != 0u && g_raw < P;
+    const unsigned g = valid ? g_raw : 0u;
+    const uint32_t pslot = my.first + (valid ? t : 0u);
+    const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot >> 1) * 8u + (pslot & 1u);
+    float ix = 0.f, iy = 0.f, iz = 0.f;
+    if (my.count) { ix = xf[0]; iy = xf[2]; if (D == 3) iz = xf[4]; }
+    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+    const uint32_t max_mass_bits = *a.max_mass_bits;
+    // lanes of an unused leaf slot hold no target: they must not drag the wave into the guarded loop
+    const bool in_close_set = my.count != 0u && !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
+    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
+    // this leaf's copy runs and the length of its stream
+    for (unsigned k = lw; k < my.op_n; k += w) {
+        const CopyOp o = a.ops[my.op_lo + k];
+        op_end[sub][k] = o.end;
+        op_base[sub][k] = o.base;
+    }
+    const uint32_t u_end = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end : 0u;
+    float4* __restrict__ region = tile + sub * (R + (unsigned)kPackPadUnits);
+    const bool odd_unit = (lw & 1u) != 0u;
+    const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
+    const float4 pad_unit = make_float4(pad_xy, pad_xy, pad_zm, pad_zm);
+    for (unsigned k = lw; k < (unsigned)kPackPadUnits + (sub + 1u == 64u / w ? 16u : 0u); k += w) region[R + k] = pad_unit;   // written once: staging never touches them
+    Sums<D> S;
+    osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
+    S.o = &osum[0][lane];
+    S.stride = 64u;
+    const unsigned inv_P = (65536u + P - 1u) / P;
+    const unsigned pairs = R >> 1;
+    const unsigned T = (((pairs + P - 1u) * inv_P) >> 16) | 1u;     // the same for every lane of the wave
+    __syncthreads();                                               // the run tables (one wave: cheap)
+    unsigned k = 0;                                                // this lane's cursor in its leaf's runs; only ever moves forward
+    for (uint32_t it = 0; it < tiles; ++it) {
+        const uint32_t u0 = it * R;
+        float4 v[kPackUnitsPerLane];
+#pragma unroll
+        for (int j = 0; j < kPackUnitsPerLane; ++j) {
+            const uint32_t u = u0 + lw + (uint32_t)j * w;
+            v[j] = pad_unit;
+            if (u < u_end) {
+                while (u >= op_end[sub][k]) ++k;
+                v[j] = a.xp[op_base[sub][k] + u];
+            }
+        }
+        __syncthreads();                                           // the previous tile has been consumed
+#pragma unroll
+        for (int j = 0; j < kPackUnitsPerLane; ++j) region[lw + (unsigned)j * w] = v[j];
+        __syncthreads();
+        const float4* s = region + 2u * g * T;
+        if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
+        else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
+    }
+    S.flush();
+    __syncthreads();
+    if (valid && g == 0u) {
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+        const unsigned l0 = sub * w + t;
+        for (unsigned q = 0; q < P; ++q) { ox += osum[0][l0 + q * W]; oy += osum[1][l0 + q * W]; oz += osum[2][l0 + q * W]; }
+        a.acc[pslot] = ox;
+        a.acc[(size_t)a.pslots + pslot] = oy;
+        if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
+    }
+}
+
 // staged Body<D> AoS fp64 (host order) -> leaf-ordered source pairs, fp32; a padded slot without a body is massless and far away
 __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restrict__ raw, size_t stride_d, int dim,
                                                           const uint32_t* __restrict__ pslot_body, uint32_t pslots, float* __restrict__ xp,
@@ -422,6 +521,14 @@ LeafKernel pick(int dim, int law, int waves) {
         {{leaf_pair_kernel<2, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, 2>},
          {leaf_pair_kernel<3, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, 2>}}};
     return table[waves - 1][dim - 2][law];
+}
+
+typedef void (*PackKernel)(LeafPackArgs);
+PackKernel pick_pack(int dim, int law) {
+    static const PackKernel table[2][3] = {
+        {leaf_pack_kernel<2, NBX_LAW_BRUTE>, leaf_pack_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_pack_kernel<3, NBX_LAW_BRUTE>, leaf_pack_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<3, NBX_LAW_FMM_P2P>}};
+    return table[dim - 2][law];
 }
 
 // The call's device arrays are one allocation, and a tree code calls once per step with arrays of the same size: the allocation
@@ -614,10 +721,11 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     const int waves = plan.waves;
 
     // one allocation for the call's other device arrays (each hipFree of a large buffer costs 0.2 ms on this runtime)
-    const size_t sizes[7] = {pslots * sizeof(float4), (size_t)dim * pslots * sizeof(double), n * (size_t)dim * sizeof(double),
-                             pslots * sizeof(uint32_t), ops.size() * sizeof(CopyOp), blocks.size() * sizeof(LeafBlock), sizeof(uint32_t)};
-    size_t offs[7], total_bytes = 0;
-    for (int i = 0; i < 7; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
+    const size_t sizes[9] = {pslots * sizeof(float4), (size_t)dim * pslots * sizeof(double), n * (size_t)dim * sizeof(double),
+                             pslots * sizeof(uint32_t), ops.size() * sizeof(CopyOp), blocks.size() * sizeof(LeafBlock), sizeof(uint32_t),
+                             plan.pack_subs.size() * sizeof(PackSub), plan.pack_blocks.size() * sizeof(PackBlock)};
+    size_t offs[9], total_bytes = 0;
+    for (int i = 0; i < 9; ++i) { offs[i] = total_bytes; total_bytes += (sizes[i] + 255) / 256 * 256 + 256; }
     NBX_HIP_TRY(take_arena(device, total_bytes, &d.arena, &d.arena_bytes));
     char* const arena = d.arena;
     float4* xp = reinterpret_cast<float4*>(arena + offs[0]);
@@ -627,11 +735,17 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     CopyOp* d_ops = reinterpret_cast<CopyOp*>(arena + offs[4]);
     LeafBlock* d_blocks = reinterpret_cast<LeafBlock*>(arena + offs[5]);
     uint32_t* d_max_mass = reinterpret_cast<uint32_t*>(arena + offs[6]);
+    PackSub* d_subs = reinterpret_cast<PackSub*>(arena + offs[7]);
+    PackBlock* d_packs = reinterpret_cast<PackBlock*>(arena + offs[8]);
     if (copier.joinable()) copier.join();
     NBX_HIP_TRY(copy_rc);
     NBX_HIP_TRY(hipMemcpyAsync(d_pb, pslot_body.data(), pslots * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     if (!ops.empty()) NBX_HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(CopyOp), hipMemcpyHostToDevice, d.stream));
-    NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(LeafBlock), hipMemcpyHostToDevice, d.stream));
+    if (!blocks.empty()) NBX_HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(LeafBlock), hipMemcpyHostToDevice, d.stream));
+    if (!plan.pack_blocks.empty()) {
+        NBX_HIP_TRY(hipMemcpyAsync(d_subs, plan.pack_subs.data(), sizes[7], hipMemcpyHostToDevice, d.stream));
+        NBX_HIP_TRY(hipMemcpyAsync(d_packs, plan.pack_blocks.data(), sizes[8], hipMemcpyHostToDevice, d.stream));
+    }
     NBX_HIP_TRY(hipMemsetAsync(dforces, 0, n * (size_t)dim * sizeof(double), d.stream));
     NBX_HIP_TRY(hipMemsetAsync(d_max_mass, 0, sizeof(uint32_t), d.stream));
     (void)hipGetLastError();
@@ -642,8 +756,16 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     LeafArgs a;
     a.xp = xp; a.pslots = (uint32_t)pslots; a.ops = d_ops; a.blocks = d_blocks; a.acc = acc; a.max_mass_bits = d_max_mass;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
-    NBX_HIP_TRY(hipGetLastError());
+    if (!blocks.empty()) {   // one-leaf workgroups first: they are the long ones
+        hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
+        NBX_HIP_TRY(hipGetLastError());
+    }
+    if (!plan.pack_blocks.empty()) {
+        LeafPackArgs pa;
+        pa.xp = xp; pa.pslots = (uint32_t)pslots; pa.ops = d_ops; pa.blocks = d_packs; pa.subs = d_subs; pa.acc = acc; pa.max_mass_bits = d_max_mass;
+        hipLaunchKernelGGL(pick_pack(dim, law), dim3((unsigned)plan.pack_blocks.size()), dim3(64), 0, d.stream, pa);
+        NBX_HIP_TRY(hipGetLastError());
+    }
     NBX_HIP_TRY(hipEventRecord(d.ev1, d.stream));
     const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
     hipLaunchKernelGGL(leaf_scatter_kernel, dim3(gs), dim3(256), 0, d.stream, acc, raw, stride_bytes / sizeof(double), dim, d_pb, (uint32_t)pslots,
@@ -661,8 +783,8 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
 // fp32 source copy), pair kernel, and -- only if the caller wants them on the host -- forces by body and one copy out.
 struct nbx_leaf_plan {
     int device = 0, dim = 3, waves = 2;
-    size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0;
-    char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass
+    size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0, n_subs = 0, n_packs = 0;
+    char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass | packed leaves | packed waves
     float4* xp = nullptr;
     double* sums = nullptr;         // [dim][pslots]
     uint32_t* pslot_body = nullptr; // [pslots]
@@ -670,6 +792,8 @@ struct nbx_leaf_plan {
     CopyOp* ops = nullptr;
     LeafBlock* blocks = nullptr;
     uint32_t* max_mass = nullptr;
+    PackSub* subs = nullptr;
+    PackBlock* packs = nullptr;
     double* forces = nullptr;       // [n][dim], allocated when a caller first asks for forces on the host
     double* raw = nullptr;          // staged Body<D> array of nbx_leaf_plan_forces, allocated on first use
     size_t raw_bytes = 0;
@@ -705,12 +829,20 @@ int plan_mark_done(nbx_leaf_plan* p, hipStream_t s) {
 }
 
 int plan_launch_pairs(nbx_leaf_plan* p, int law, hipStream_t s, bool timed) {
-    if (p->n_blocks == 0) return NBX_OK;
-    LeafArgs a;
-    a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
+    if (p->n_blocks == 0 && p->n_packs == 0) return NBX_OK;
     if (timed) NBX_HIP_TRY(hipEventRecord(p->ev0, s));
-    hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
-    NBX_HIP_TRY(hipGetLastError());
+    if (p->n_blocks) {
+        LeafArgs a;
+        a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
+        hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
+        NBX_HIP_TRY(hipGetLastError());
+    }
+    if (p->n_packs) {
+        LeafPackArgs pa;
+        pa.xp = p->xp; pa.pslots = (uint32_t)p->pslots; pa.ops = p->ops; pa.blocks = p->packs; pa.subs = p->subs; pa.acc = p->sums; pa.max_mass_bits = p->max_mass;
+        hipLaunchKernelGGL(pick_pack(p->dim, law), dim3((unsigned)p->n_packs), dim3(64), 0, s, pa);
+        NBX_HIP_TRY(hipGetLastError());
+    }
     if (timed) NBX_HIP_TRY(hipEventRecord(p->ev1, s));
     return NBX_OK;
 }
@@ -748,6 +880,7 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
     p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;
     p->pslots = host.pslots(); p->n_ops = host.ops.size(); p->n_blocks = host.blocks.size();
+    p->n_subs = host.pack_subs.size(); p->n_packs = host.pack_blocks.size();
     std::vector<uint32_t> body_slot;
     try { body_slot.assign(n, 0xffffffffu); } catch (...) { delete p; return fail(NBX_ERR_ALLOC, "host allocation failed"); }
     for (size_t s = 0; s < p->pslots; ++s)
@@ -763,10 +896,11 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-    const size_t sizes[7] = {p->pslots * sizeof(float4), (size_t)dim * p->pslots * sizeof(double), p->pslots * sizeof(uint32_t),
-                             n * sizeof(uint32_t), p->n_ops * sizeof(CopyOp), p->n_blocks * sizeof(LeafBlock), sizeof(uint32_t)};
-    size_t offs[7], total = 0;
-    for (int i = 0; i < 7; ++i) { offs[i] = total; total += (sizes[i] + 255) / 256 * 256 + 256; }
+    const size_t sizes[9] = {p->pslots * sizeof(float4), (size_t)dim * p->pslots * sizeof(double), p->pslots * sizeof(uint32_t),
+                             n * sizeof(uint32_t), p->n_ops * sizeof(CopyOp), p->n_blocks * sizeof(LeafBlock), sizeof(uint32_t),
+                             p->n_subs * sizeof(PackSub), p->n_packs * sizeof(PackBlock)};
+    size_t offs[9], total = 0;
+    for (int i = 0; i < 9; ++i) { offs[i] = total; total += (sizes[i] + 255) / 256 * 256 + 256; }
     PLAN_TRY(hipMalloc((void**)&p->arena, total));
     p->xp = reinterpret_cast<float4*>(p->arena + offs[0]);
     p->sums = reinterpret_cast<double*>(p->arena + offs[1]);
@@ -775,6 +909,12 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     p->ops = reinterpret_cast<CopyOp*>(p->arena + offs[4]);
     p->blocks = reinterpret_cast<LeafBlock*>(p->arena + offs[5]);
     p->max_mass = reinterpret_cast<uint32_t*>(p->arena + offs[6]);
+    p->subs = reinterpret_cast<PackSub*>(p->arena + offs[7]);
+    p->packs = reinterpret_cast<PackBlock*>(p->arena + offs[8]);
+    if (p->n_packs) {
+        PLAN_TRY(hipMemcpyAsync(p->subs, host.pack_subs.data(), sizes[7], hipMemcpyHostToDevice, p->stream));
+        PLAN_TRY(hipMemcpyAsync(p->packs, host.pack_blocks.data(), sizes[8], hipMemcpyHostToDevice, p->stream));
+    }
     if (p->pslots) PLAN_TRY(hipMemcpyAsync(p->pslot_body, host.pslot_body.data(), sizes[2], hipMemcpyHostToDevice, p->stream));
     if (n) PLAN_TRY(hipMemcpyAsync(p->body_slot, body_slot.data(), sizes[3], hipMemcpyHostToDevice, p->stream));
     if (p->n_ops) PLAN_TRY(hipMemcpyAsync(p->ops, host.ops.data(), sizes[4], hipMemcpyHostToDevice, p->stream));
@@ -808,7 +948,7 @@ int nbx_leaf_plan_info(const nbx_leaf_plan* p, size_t* slots, size_t* runs, size
     if (!p) return fail(NBX_ERR_INVALID, "plan is null");
     if (slots) *slots = p->pslots;
     if (runs) *runs = p->n_ops;
-    if (workgroups) *workgroups = p->n_blocks;
+    if (workgroups) *workgroups = p->n_blocks + p->n_packs;
     if (waves) *waves = p->waves;
     return NBX_OK;
 }
@@ -845,7 +985,7 @@ int nbx_leaf_plan_forces(nbx_leaf_plan* p, const void* bodies, size_t stride_byt
     p->last_mass = p->raw + 2 * p->dim; p->last_mass_stride = stride_bytes / sizeof(double);
     if ((rc = plan_mark_done(p, s))) return rc;
     if ((rc = plan_forces_out(p, s, forces_out))) return rc;
-    if (kernel_ms && p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
+    if (kernel_ms && (p->n_blocks || p->n_packs)) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
     return NBX_OK;
 }
 
@@ -874,7 +1014,7 @@ int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, do
     if ((rc = plan_mark_done(p, s))) return rc;
     if (forces_out) { if ((rc = plan_forces_out(p, s, forces_out))) return rc; }
     else if (kernel_ms) NBX_HIP_TRY(hipStreamSynchronize(s));
-    if (kernel_ms && p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
+    if (kernel_ms && (p->n_blocks || p->n_packs)) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
     return NBX_OK;
 }
 
@@ -924,7 +1064,7 @@ int nbx_leaf_plan_time_kernel(nbx_leaf_plan* p, int law, int reps, float* mean_m
     }
     NBX_HIP_TRY(hipEventRecord(p->ev1, s));
     NBX_HIP_TRY(hipStreamSynchronize(s));
-    if (p->n_blocks) NBX_HIP_TRY(hipEventElapsedTime(mean_ms, p->ev0, p->ev1));
+    if (p->n_blocks || p->n_packs) NBX_HIP_TRY(hipEventElapsedTime(mean_ms, p->ev0, p->ev1));
     *mean_ms /= (float)(reps - timed_from);
     // the sums now belong to `law`: keep the bookkeeping of the last evaluation consistent with them
     p->last_signedG = (law == NBX_LAW_BRUTE) ? -std::fabs(p->last_signedG) : std::fabs(p->last_signedG);

@@ -22,6 +22,28 @@ struct LeafBlock {     // one workgroup; read with scalar loads
     Piece piece[2];
 };
 static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
+// ---- packed small leaves (round 4) ----
+// A leaf of a few bodies cannot fill a wave: at 4 bodies per leaf a workgroup's start-up, staging and closing reduction cost ten
+// times its pair arithmetic (0.06 of the fp32 peak in round 3).  Leaves of up to kPackMaxTargets bodies whose list is at most
+// kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 8 or 16 lanes --
+// its own copy runs, its own region of the LDS tile, P = floor(w / bodies) lanes per target (the block's smallest, so that every
+// lane of the wave runs the same trip count) -- and all of them run the pair loop together.  Everything else (larger leaves,
+// longer lists) keeps the one-leaf workgroups above.
+constexpr int kPackMaxTargets = 16;
+constexpr int kPackMaxOps = 16;
+constexpr int kPackUnitsPerLane = 8;           // a sub-leaf's tile is 8 w units: 64 (w = 8) or 128 (w = 16) bodies
+struct PackSub {                               // one packed leaf
+    uint32_t op_lo, op_n;                      // its copy runs
+    uint32_t first, count;                     // its targets (padded slots)
+};
+struct PackBlock {                             // one wave64; read with scalar loads
+    uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
+    uint32_t w, P;                             // lanes per leaf (8 | 16), lanes per target (1 .. 8)
+    uint32_t tiles;                            // tile iterations: ceil(longest stream / (kPackUnitsPerLane * w))
+    uint32_t pad_[3];
+};
+static_assert(sizeof(PackSub) == 16 && sizeof(PackBlock) == 32, "read with vector / scalar loads");
+
 struct CopyOp {
     uint32_t end;      // length of the leaf's source stream up to and including this run, in 16-byte units
     uint32_t base;     // unit of the run's first body minus the stream position it lands on (mod 2^32): source = base + position
@@ -59,15 +81,17 @@ struct LeafPlan {
     std::vector<uint32_t> pslot_body;   // [pslots] body of each padded slot, 0xffffffff for a leaf's pad
     std::vector<CopyOp> ops;            // every leaf's source list as runs of consecutive units
     std::vector<uint32_t> op_off;       // [n_leaves + 1] leaf l's runs: ops[op_off[l] .. op_off[l+1])
-    std::vector<LeafBlock> blocks;      // the workgroups, longest first
-    int waves = kMaxWaves;              // wave64 per workgroup of this launch
+    std::vector<LeafBlock> blocks;      // the one-leaf workgroups, longest first
+    int waves = kMaxWaves;              // wave64 per one-leaf workgroup of this launch
+    std::vector<PackSub> pack_subs;     // packed small leaves ...
+    std::vector<PackBlock> pack_blocks; // ... and the waves that take them, longest first
     size_t pslots() const { return unit_off.empty() ? 0 : unit_off.back(); }
 };
 
 // The CSR arrays must have been validated (offsets non-decreasing from 0, every index in range).  Returns nullptr, or why the
 // structure cannot be laid out (more than 2^32 units).
 inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
-                               const uint32_t* list_sources, LeafPlan& plan) {
+                               const uint32_t* list_sources, LeafPlan& plan, bool pack_small_leaves = true) {
     const size_t slots = n_leaves ? leaf_offsets[n_leaves] : 0;
     const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
     // padded slots: a leaf of odd size gets one more slot, so that every leaf is a run of whole source pairs
@@ -129,9 +153,47 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     std::vector<LeafBlock>& blocks = plan.blocks;
     blocks.clear();
     blocks.reserve(n_leaves);
+    // packed waves: consecutive small leaves, greedily -- a leaf joins the open wave if the wave's lane width (the next power of
+    // two >= its largest leaf, at least 8) still leaves room for one more leaf
+    std::vector<PackSub>& subs = plan.pack_subs;
+    std::vector<PackBlock>& packs = plan.pack_blocks;
+    subs.clear();
+    packs.clear();
+    uint32_t open_w = 0, open_cmax = 0, open_stream = 0;   // the open wave: lane width, largest leaf, longest stream (units)
+    auto close_pack = [&]() {
+        if (!open_w) return;
+        PackBlock& b = packs.back();
+        b.w = open_w;
+        uint32_t P = open_w / open_cmax;
+        b.P = P > (uint32_t)kMaxLanesPerTarget ? (uint32_t)kMaxLanesPerTarget : P;
+        const uint32_t tile_units = (uint32_t)kPackUnitsPerLane * open_w;
+        b.tiles = (open_stream + tile_units - 1u) / tile_units;
+        open_w = 0;
+    };
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (!c) continue;
+        const uint32_t n_ops = op_off[l + 1] - op_off[l];
+        if (pack_small_leaves && c <= (uint32_t)kPackMaxTargets && n_ops <= (uint32_t)kPackMaxOps) {
+            const uint32_t need_w = c <= 8u ? 8u : 16u;
+            const uint32_t stream = n_ops ? ops[op_off[l] + n_ops - 1].end : 0u;
+            if (open_w) {
+                const uint32_t w2 = open_w > need_w ? open_w : need_w;
+                if (packs.back().n_sub + 1u <= 64u / w2) open_w = w2;
+                else close_pack();
+            }
+            if (!open_w) {
+                PackBlock b{};
+                b.sub_lo = (uint32_t)subs.size();
+                packs.push_back(b);
+                open_w = need_w; open_cmax = 0; open_stream = 0;
+            }
+            subs.push_back(PackSub{op_off[l], n_ops, unit_off[l], c});
+            ++packs.back().n_sub;
+            if (c > open_cmax) open_cmax = c;
+            if (stream > open_stream) open_stream = stream;
+            continue;
+        }
         const uint32_t groups = (c + per_group - 1u) / per_group;
         uint32_t f = unit_off[l];
         for (uint32_t gi = 0; gi < groups; ++gi) {
@@ -152,6 +214,17 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             blocks.push_back(b);
             f += share;
         }
+    }
+    close_pack();
+    if (packs.size() > 1) {   // longest first, stable (leaf order kept among waves of equal length)
+        std::vector<PackBlock> sorted(packs);
+        uint32_t longest = 0;
+        for (const PackBlock& b : packs) if (b.tiles > longest) longest = b.tiles;
+        std::vector<uint32_t> start(longest + 2, 0u);
+        for (const PackBlock& b : packs) ++start[longest - b.tiles + 1u];
+        for (uint32_t k = 0; k <= longest; ++k) start[k + 1] += start[k];
+        for (const PackBlock& b : packs) sorted[start[longest - b.tiles]++] = b;
+        packs.swap(sorted);
     }
     // Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
     // short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).

@@ -569,14 +569,14 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
         const int splits = auto_splits(c, c->variant);
         size_t want = 2 * arena_round((size_t)dim * pad * sizeof(double)) + arena_round(pad * sizeof(double));
         want += arena_round(n_total * body + 16) + arena_round(3 * sizeof(unsigned long long));
-        want += 2 * arena_round((size_t)splits * dim * pad * sizeof(float));
+        want += 2 * arena_round((size_t)splits * variant_planes(c->variant) * dim * pad * sizeof(float));   // acc and the close-set side path's
         want += 3 * arena_round(pad * sizeof(unsigned)) + arena_round((size_t)dim * pad * sizeof(float)) + arena_round(16)
                 + arena_round((size_t)dim * n_shards * pad * sizeof(float));
         if (n_shards == 1) want += arena_round((size_t)dim * pad * sizeof(float)) + arena_round(pad * sizeof(float));
         if (c->refine_tol > 0.0) {   // mixed mode (the default): spread sums per slice, the list, the fp64 pass's sums
             size_t list_bytes = 0, acc_bytes = 0;
             strict_sizes(c, &list_bytes, &acc_bytes);
-            want += arena_round((size_t)splits * pad * sizeof(float)) + arena_round(list_bytes) + arena_round(acc_bytes);
+            want += arena_round((size_t)splits * variant_planes(c->variant) * pad * sizeof(float)) + arena_round(list_bytes) + arena_round(acc_bytes);
         }
         if (want <= ((size_t)64 << 30)) {   // beyond that the pieces are allocated one by one, and fail one by one
             void* a = nullptr;

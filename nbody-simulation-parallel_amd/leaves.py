@@ -67,3 +67,55 @@ def all_pairs_leaves(n: int, leaf_size: int):
     list_offsets = (np.arange(n_leaves + 1) * n_leaves).astype(np.uint32)
     list_sources = np.tile(np.arange(n_leaves, dtype=np.uint32), n_leaves)
     return leaf_offsets, leaf_bodies, list_offsets, list_sources
+
+
+def median_split_leaves(bodies: np.ndarray, dim: int, max_leaf_size: int = 16, reach: float = 1.0):
+    """Leaves the way the reference's BVH makes them -- BVH<D>::build_recursive (nbody-sim-new/bvh.cpp:34-73): split the bodies at
+    the median along the longest axis of their bounding box until a node holds at most max_leaf_size (methods.h:57: 16) -- with a
+    near-field list per leaf: the leaf itself first, then every other leaf whose bounding box comes within `reach` x the leaf's own
+    box diagonal of its box (box-to-box distance, the kind of acceptance test a traversal applies).  Leaves come out in tree
+    order (depth first, lower half first), which keeps spatial neighbours close in leaf order.  Host-side numpy; a stand-in for a
+    tree builder in tests and timing, not a port of the reference's pointer tree."""
+    pos = np.asarray(bodies)[:, :dim]
+    n = pos.shape[0]
+    if n == 0:
+        z = np.zeros(1, dtype=np.uint32)
+        return z, np.zeros(0, dtype=np.uint32), z.copy(), np.zeros(0, dtype=np.uint32)
+    order = np.arange(n)
+    leaves = []
+    stack = [(0, n)]
+    while stack:
+        lo, hi = stack.pop()
+        if hi - lo <= max_leaf_size:
+            leaves.append((lo, hi))
+            continue
+        idx = order[lo:hi]
+        p = pos[idx]
+        axis = int(np.argmax(p.max(axis=0) - p.min(axis=0)))
+        mid = (hi - lo) // 2
+        part = np.argpartition(p[:, axis], mid)
+        order[lo:hi] = idx[part]
+        stack.append((lo + mid, hi))      # popped second: the lower half's subtree comes out first
+        stack.append((lo, lo + mid))
+    leaves.sort()
+    leaf_offsets = np.array([l for l, _ in leaves] + [n], dtype=np.uint32)
+    nl = len(leaves)
+    bmin = np.array([pos[order[l:h]].min(axis=0) for l, h in leaves])
+    bmax = np.array([pos[order[l:h]].max(axis=0) for l, h in leaves])
+    diag = np.linalg.norm(bmax - bmin, axis=1)
+    centre = 0.5 * (bmin + bmax)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(centre)
+    # candidates by centre distance (a superset), then the exact box-to-box distance
+    half = 0.5 * diag
+    cand = tree.query_ball_point(centre, r=(1.0 + reach) * diag + half.max())
+    list_offsets, list_sources = [0], []
+    for l in range(nl):
+        c = np.asarray(cand[l], dtype=np.int64)
+        c = c[c != l]
+        gap = np.maximum(0.0, np.maximum(bmin[c] - bmax[l], bmin[l] - bmax[c]))
+        near = c[np.linalg.norm(gap, axis=1) <= reach * diag[l]]
+        list_sources.append(l)
+        list_sources.extend(np.sort(near).tolist())
+        list_offsets.append(len(list_sources))
+    return (leaf_offsets, order.astype(np.uint32), np.asarray(list_offsets, dtype=np.uint32), np.asarray(list_sources, dtype=np.uint32))

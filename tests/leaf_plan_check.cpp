@@ -38,6 +38,9 @@ int main(int argc, char** argv) {
     store(d + "ops.u32", plan.ops.data(), plan.ops.size() * 8);
     store(d + "op_off.u32", plan.op_off.data(), plan.op_off.size() * 4);
     store(d + "blocks.u32", plan.blocks.data(), plan.blocks.size() * 32);
+    static_assert(sizeof(nbx_leaf::PackSub) == 16 && sizeof(nbx_leaf::PackBlock) == 32, "written as raw words");
+    store(d + "pack_subs.u32", plan.pack_subs.data(), plan.pack_subs.size() * 16);
+    store(d + "pack_blocks.u32", plan.pack_blocks.data(), plan.pack_blocks.size() * 32);
     printf("waves %d blocks %zu ops %zu pslots %zu\n", plan.waves, plan.blocks.size(), plan.ops.size(), plan.pslots());
     return 0;
 }

@@ -210,6 +210,46 @@ def test_unguarded_and_guarded_waves(nbx, oracle, dim):
         _check(nbx, oracle, c, cl, law, f"guarded and unguarded waves mixed, law {name}, D={dim}")
 
 
+@pytest.mark.parametrize("dim", (3, 2))
+@pytest.mark.parametrize("box", (1.0e7, 6.0e4, 1.0))
+def test_packed_small_leaves(nbx, oracle, dim, box):
+    """Leaves of a few bodies are PACKED several to a wave (csrc/leaf_plan.h PackBlock, leaf_pack_kernel): grid cells of ~5 bodies
+    (0 to ~15, Poisson) with 3^D-cell lists, and the reference BVH's own shape -- median-split leaves of at most 16 and at most 8
+    bodies (bvh.cpp:34-73, methods.h:57) with box-distance near-field lists.  Three coordinate regimes -- the reference generator's
+    box (nearly every wave takes the pair loop without compares), a box that straddles the close set's boundary (guarded and
+    unguarded waves side by side; within a wave, leaves on both sides), a unit box (every wave guarded) -- with identical positions
+    and sub-threshold pairs planted inside a leaf and across two leaves; all three laws; one-shot call, plan and resident plan."""
+    n = 20000
+    b = oracle.generate(160 + dim, n, dim)
+    b[:, :dim] = np.abs(b[:, :dim]) / 1.0e7 * box + (20000.0 if box == 1.0e7 else 0.0)
+    grid = nbx.leaves.uniform_grid_leaves(oracle.round_inputs_to_f32(b), dim, 4 if dim == 3 else 6)
+    lo, lb, so, ss = grid
+    sizes = np.diff(lo)
+    big = int(np.argmax(sizes))
+    assert 3 <= sizes[big] <= 16 and np.diff(so).max() <= 3 ** dim
+    i0, i1, i2 = lb[lo[big]], lb[lo[big] + 1], lb[lo[big] + 2]
+    nb = int(ss[so[big] + 1])                                       # a neighbour leaf of it
+    j0 = lb[lo[nb]]
+    b[i1, :dim] = b[i0, :dim]                                       # identical positions inside a leaf
+    b[j0, :dim] = b[i0, :dim]                                       # ... and across two leaves (stays on the neighbour's list)
+    if box <= 6.0e4:
+        b[i2, :dim] = b[i0, :dim]; b[i2, 0] += 2.0e-5 * max(box, 1.0) / 1.0     # r^2 = 4e-10 (unit box): brute counts, tree skips, fmm counts
+    b = oracle.round_inputs_to_f32(b)
+    for law, name in LAWS:
+        _check(nbx, oracle, b, grid, law, f"packed grid leaves, law {name}, D={dim}, box {box:g}")
+    for max_leaf in (16, 8):
+        tree = nbx.leaves.median_split_leaves(b, dim, max_leaf, reach=0.5)
+        tsz = np.diff(tree[0])
+        assert tsz.max() <= max_leaf and tsz.min() >= max_leaf // 2
+        _check(nbx, oracle, b, tree, nbx.LAW_TREE_LEAF, f"median-split leaves of <= {max_leaf}, D={dim}, box {box:g}")
+    with nbx.LeafPlan(n, dim, *grid) as plan:
+        slots, runs, groups, waves = plan.info()
+        assert groups < 0.5 * (sizes > 0).sum(), "small leaves must share waves"
+    heavy = b.copy()
+    heavy[int(lb[lo[0]]), -1] = 3.0e10                              # above kFastMaxMass: every wave takes the guarded loop
+    _check(nbx, oracle, heavy, grid, nbx.LAW_FMM_P2P, f"packed grid leaves, guarded by a heavy mass, D={dim}, box {box:g}")
+
+
 def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
     b = oracle.generate(1, 10, 3)
     ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
@@ -284,7 +324,7 @@ def test_plan_stepping_matches_the_reference_helpers(nbx, oracle):
     standing structure, k steps on the device, against the same loop on the host built from the oracle's leaf sums on the
     fp32-representable positions the device sees.  Strong coupling (G x 1e24) so that the forces bend the paths; bodies in no
     leaf only drift.  Per-body bound from the stated force tolerance, as in test_config2_trajectory_with_coupling."""
-    n, dim, steps, dt, scale = 8000, 3, 4, 1.5, 1e24
+    n, dim, steps, dt, scale = 8000, 3, 4, 1.5, 1e26
     b0 = oracle.round_inputs_to_f32(oracle.generate(150, n, dim))
     lo, lb, so, ss = nbx.leaves.uniform_grid_leaves(b0, dim, 2)
     keep = lo[-1] - 37                                             # the last 37 slots' bodies end up in no leaf
@@ -308,7 +348,7 @@ def test_plan_stepping_matches_the_reference_helpers(nbx, oracle):
         c.compute_accel()
         fb = c.forces(G)
     dv = np.linalg.norm(ref[:, dim:2 * dim] - b0[:, dim:2 * dim], axis=1)
-    assert np.median(dv) > 1e-5 and dv.max() > 1.0, "coupling too weak to test anything"
+    assert np.median(dv) > 1e-4 and dv.max() > 1.0, "coupling too weak to test anything"
     err = np.linalg.norm(got[:, dim:2 * dim] - ref[:, dim:2 * dim], axis=1)
     bound = 1.25 * steps * 4.0e-6 * S0 / b0[:, -1] * dt
     out = np.setdiff1d(np.arange(n), lb[:keep])

@@ -22,7 +22,10 @@ def planner(tmp_path_factory):
             np.asarray(a, dtype=np.uint32).tofile(os.path.join(workdir, name + ".u32"))
         p = subprocess.run([exe, workdir], capture_output=True, text=True)
         assert p.returncode == 0, p.stdout + p.stderr
-        out = {k: np.fromfile(os.path.join(workdir, k + ".u32"), dtype=np.uint32) for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks")}
+        out = {k: np.fromfile(os.path.join(workdir, k + ".u32"), dtype=np.uint32)
+               for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks", "pack_subs", "pack_blocks")}
+        out["pack_subs"] = out["pack_subs"].reshape(-1, 4)      # op_lo, op_n, first, count
+        out["pack_blocks"] = out["pack_blocks"].reshape(-1, 8)  # sub_lo, n_sub, w, P, tiles, -, -, -
         out["waves"] = int(p.stdout.split()[1])
         out["ops"] = out["ops"].reshape(-1, 2)          # (end, base)
         out["blocks"] = out["blocks"].reshape(-1, 8)    # op_lo, op_n, key, -, first0, count0, first1, count1
@@ -47,6 +50,10 @@ def _structure(seed, sizes, list_len):
     so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
     ss = np.concatenate(lists) if lists else np.zeros(0, dtype=np.int64)
     return lo, lb, so, ss
+
+
+def n_ops_of_leaf(op_off, l):
+    return int(op_off[l + 1]) - int(op_off[l])
 
 
 def _check(plan, lo, lb, so, ss):
@@ -82,6 +89,7 @@ def _check(plan, lo, lb, so, ss):
     for op_lo, op_n, key, _, f0, c0, f1, c1 in blocks.astype(np.int64):
         assert c0 <= 64 and c1 <= 64 and c0 + c1 >= 1 and (waves == 2 or c1 == 0)
         l = leaf_of_unit[f0 if c0 else f1]
+        assert sizes[l] > 16 or n_ops_of_leaf(op_off, l) > 16   # small leaves with short lists are packed, not here
         assert op_lo == op_off[l] and op_n == op_off[l + 1] - op_off[l]
         for f, c in ((f0, c0), (f1, c1)):
             if c:
@@ -89,6 +97,31 @@ def _check(plan, lo, lb, so, ss):
                 hit[f:f + c] += 1
         if c0 and c1:
             assert f1 == f0 + c0
+    # packed waves (leaves of <= 16 bodies with <= 16 runs): K = 64 / w leaves side by side, each on its own w lanes
+    subs, packs = plan["pack_subs"].astype(np.int64), plan["pack_blocks"].astype(np.int64)
+    n_ops_of = np.diff(op_off.astype(np.int64))
+    seen_sub = np.zeros(subs.shape[0], dtype=np.int64)
+    for sub_lo, n_sub, w, P, tiles, *_ in packs:
+        assert w in (8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
+        mine = subs[sub_lo:sub_lo + n_sub]
+        seen_sub[sub_lo:sub_lo + n_sub] += 1
+        assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 16).all()
+        assert P == min(8, w // mine[:, 3].max())
+        assert w == (8 if mine[:, 3].max() <= 8 else 16) or n_sub == 1 or w == 16
+        streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
+        assert tiles == -(-max(streams) // int(8 * w))
+        for o, k, f, c in mine:
+            l = leaf_of_unit[f]
+            assert sizes[l] == c and f == unit_off[l] and o == op_off[l] and k == n_ops_of[l]
+            assert (pslot_body[f:f + c] != PAD).all()
+            hit[f:f + c] += 1
+    assert (seen_sub == 1).all()
+    if packs.shape[0] > 1:
+        assert (np.diff(packs[:, 4]) <= 0).all()                # longest first
+    # a leaf is packed exactly when it is small and its list short
+    packed_leaves = set(leaf_of_unit[subs[:, 2]].tolist()) if subs.shape[0] else set()
+    for l in range(sizes.size):
+        assert (l in packed_leaves) == (1 <= sizes[l] <= 16 and n_ops_of[l] <= 16), l
     assert (hit == (pslot_body != PAD)).all()
     # launch order: longest first (1024 duration classes)
     key = blocks[:, 2].astype(np.int64)

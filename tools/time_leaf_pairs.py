@@ -1,6 +1,9 @@
 """Near-field (leaf-pair) direct sums at FMM-like sizes: N bodies in a uniform grid of leaves (2^(3*level) cells), every
 leaf against its 27-cell neighbourhood, through nbx_leaf_pair_forces (one-shot) and nbx_leaf_plan_* (resident); prints the kernel's own time per law.
-    python tools/time_leaf_pairs.py [N] [level] [box]
+    python tools/time_leaf_pairs.py [N] [level | bvh<K>] [box]
+level: uniform grid of 2^level cells per axis with 27-cell lists (5: 32 bodies per leaf at N = 2^20, 6: 4 bodies per leaf);
+bvh<K> (e.g. bvh16): median-split leaves of at most K bodies, the reference BVH's own (bvh.cpp:34-73, methods.h:57), with
+box-distance near-field lists (leaves.median_split_leaves).
 box (default: the reference generator's 1e7) rescales the positions: in a box below 2^14 = 16,384 every target lies inside the
 close set (csrc/nbx_internal.h) and every wave takes the kernel's guarded pair loop."""
 import os, sys, time
@@ -9,11 +12,16 @@ import numpy as np
 import nbody_amd as nbx
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-level = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+shape = sys.argv[2] if len(sys.argv) > 2 else "5"
 b = nbx.uniform_bodies(n, 3, 5)
 if len(sys.argv) > 3:
     b[:, :3] *= float(sys.argv[3]) / 1.0e7
-leaves = nbx.leaves.uniform_grid_leaves(b, 3, level)
+t_build = time.perf_counter()
+if shape.startswith("bvh"):
+    leaves = nbx.leaves.median_split_leaves(b, 3, int(shape[3:] or 16), reach=0.5)
+else:
+    leaves = nbx.leaves.uniform_grid_leaves(b, 3, int(shape))
+print(f"leaves '{shape}' built on the host in {time.perf_counter() - t_build:.1f} s (not part of any timing below)", flush=True)
 lo, _, so, ss = leaves
 sizes = np.diff(lo).astype(np.int64)
 src = np.add.reduceat(sizes[ss], so[:-1])          # bodies on each leaf's list (every list here is non-empty)
