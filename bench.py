@@ -441,6 +441,7 @@ def main():
             "config": {"workload": f"N={N} {args.dim}D uniform-random bodies (reference generator ranges, seed {args.seed}), "
                                    "one all-pairs force evaluation + fused kick/drift per step",
                        "n_bodies": N, "dim": args.dim, "lds_tile": 256, "kernel_variant": variant_name, "source_slices": source_splits,
+                       "acc_planes": source_splits * (2 if variant_name.startswith(("fastpk3l", "strict")) else 1),   # fp32 planes of partial sums: {hi, lo} per slice for the fp64-sum kernels
                        "parallelism": "1 GPU" if world == 1 else f"{world} target shards, RCCL all-gather of positions per step"},
             # bound: the compute roofline of the two the contract names ("hbm" | "mfma").  The kernel issues no MFMA
             # (north star); its limit is fp32 VALU issue, and on MI355X the fp32 matrix peak equals the fp32 vector

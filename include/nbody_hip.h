@@ -81,7 +81,8 @@ int nbx_release_cached(void);
  * Same argument ranges as nbx_ctx_set_refine (NBX_ERR_INVALID otherwise). */
 int nbx_set_default_refine(double rel_tolerance, double sigma_factor);
 int nbx_get_default_refine(double* rel_tolerance, double* sigma_factor);
-/* The calibrated sigma factor the mixed mode uses for `dim` when the caller passes 0 (tests pin it). */
+/* The calibrated sigma factor the mixed mode uses for `dim` with the default (three-level) force kernel when the caller passes 0
+ * (24 in 3D, 32 in 2D; tests pin it).  The two-level variant "fastpk_t8_w3_u4", selected by name, keeps round 3's 48 / 64. */
 double nbx_refine_sigma_default(int dim);
 
 /* ---- one-shot entry points (host memory in, host memory out) --------------------------------- */

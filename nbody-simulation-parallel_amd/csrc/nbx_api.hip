@@ -96,13 +96,18 @@ constexpr int kEventPairs = 512;
 constexpr int kMaxSplits = 256;
 constexpr int kPhiSlices = 16;
 constexpr int kGraphMinSteps = 4;   // nbx_ctx_step replays a captured step from this many steps on
-// Mixed mode: selection rule |a|^2 < (sigma u / tol)^2 Q (force_kernel.hip).  The default sigma factor is calibrated on all
-// bodies of BASELINE's uniform 3D input at N = 2^20 and of config 5's Plummer sphere at N = 2^22 against the strict kernel
-// (profiles/r3/mixed_mode_calibration.txt): 48 lists every body above 1e-5 of the six 3D inputs surveyed.
-// Plane sums cancel harder (the uniform 2D input at N = 2^20 has 3,006 bodies above 1e-5 where the 3D one has 39): there 48
-// missed 8 of them and 64 none (profiles/r3/accuracy_more_inputs_cap16384.jsonl, rule_sigma_*), at 5 % of the bodies listed.
-constexpr double kRefineSigmaDefault3D = 48.0;
-constexpr double kRefineSigmaDefault2D = 64.0;
+// Mixed mode: selection rule |a|^2 < (sigma u / tol)^2 Q (force_kernel.hip).  The sigma factor is a calibration of the DEFAULT
+// kernel's summation (round 4: the three-level kernel, whose rounding errors are ~3x smaller than the two-level kernel's at the same
+// spread Q -- the factor a body NEEDS, error / (u sqrt(Q)), peaks at 17-19 over 1-4 million bodies where it peaked at 62), taken
+// from all-bodies surveys against the strict kernel on ten inputs (profiles/r4/all_bodies_3l.jsonl): uniform
+// 3D N = 2^20 (three seeds) and 2^22, Plummer 2^22, 64 Gaussian clumps, a lattice in index order with random and with equal
+// masses, uniform 2D N = 2^20 and 2^22.  With 24 (3D) no body of any 3D input is left above 5.8e-6 (tolerance 1e-5), with 32 (2D)
+// none above 4.7e-6; the next smaller factors tried (20 / 24) leave 6.7e-6 / 6.3e-6.  Round 3's factors for the two-level kernel
+// were 48 / 64 (7.6e-6 to 9.8e-6 left): the two-level variant, when selected by name, still gets those.
+constexpr double kRefineSigmaDefault3D = 24.0;
+constexpr double kRefineSigmaDefault2D = 32.0;
+constexpr double kRefineSigmaTwoLevel3D = 48.0;
+constexpr double kRefineSigmaTwoLevel2D = 64.0;
 constexpr double kUnitRoundoffF32 = 0x1p-24;
 // Precision default of new contexts (nbx_set_default_refine): the north star's tolerance for every body
 std::atomic<double> g_default_refine_tol{1.0e-5};
@@ -316,7 +321,11 @@ RefineLaunch refine_launch(const nbx_ctx* c) {
     R.base.counters = c->counters; R.base.bad_flag = c->bad_flag; R.base.qsum = c->qsum;
     R.strict_list = c->strict_list; R.strict_acc = c->strict_acc; R.strict_cap = c->strict_cap; R.strict_slices = c->strict_slices;
     R.strict_budget = c->strict_budget;
-    const double r = (c->refine_sigma > 0.0 ? c->refine_sigma : c->dim == 2 ? kRefineSigmaDefault2D : kRefineSigmaDefault3D) * kUnitRoundoffF32 / c->refine_tol;
+    const bool three_level = variant_planes(c->variant) == 2;   // of the fast kernels only the three-level one writes {hi, lo} planes
+    const double sigma = c->refine_sigma > 0.0 ? c->refine_sigma
+                         : three_level ? (c->dim == 2 ? kRefineSigmaDefault2D : kRefineSigmaDefault3D)
+                                       : (c->dim == 2 ? kRefineSigmaTwoLevel2D : kRefineSigmaTwoLevel3D);
+    const double r = sigma * kUnitRoundoffF32 / c->refine_tol;
     R.c2 = r * r;
     R.grid_slices = c->splits / variant_planes(c->variant);
     return R;

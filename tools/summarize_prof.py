@@ -61,7 +61,7 @@ def main():
         cfg = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())["config"]
     except Exception:
         pass
-    n, S = cfg.get("n_bodies"), cfg.get("source_slices")
+    n, S = cfg.get("n_bodies"), cfg.get("acc_planes", cfg.get("source_slices"))   # planes of partial sums the consumers read
     if n and S:
         known = {"classify_close_kernel": (12.0 * n, None), "classify_sources_kernel": (12.0 * n, None),
                  "kick_drift_kernel": ((12.0 * S + 56.0) * n, 60.0 * n)}
