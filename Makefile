@@ -47,7 +47,7 @@ $(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c $< -o $@
 
 $(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/leaf_plan.h $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(LEAF_DEFS) -c $< -o $@
 
 $(LIB): $(OBJS) $(CSRC)/libnbody_hip.map
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl -Wl,--version-script=$(CSRC)/libnbody_hip.map

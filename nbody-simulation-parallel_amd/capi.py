@@ -21,7 +21,7 @@ SRC_ALL, SRC_LOCAL, SRC_REMOTE = 0, 1, 2
 REFERENCE_G = 4.471e-21  # nbody-sim-new/utils.h:21
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libnbody_hip.so")
+LIB_PATH = os.environ.get("NBODY_HIP_LIBRARY") or os.path.join(_PKG_DIR, "libnbody_hip.so")   # the override is for A/B builds (tools/)
 
 # every symbol include/nbody_hip.h declares: (name, restype, argtypes)
 _c = ctypes

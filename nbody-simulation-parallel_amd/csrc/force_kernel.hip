@@ -357,7 +357,10 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
     __shared__ Tile64 tile[2][kTile];
     const unsigned tid = threadIdx.x;
     unsigned bx, by;
-    if (LIST) { bx = blockIdx.x; by = blockIdx.y; } else xcd_tile(bx, by);
+    // LIST: x = source slice, y = list-block row.  Consecutive workgroups (dealt round-robin to the 8 XCDs) are then the slices of ONE
+    // list block: a short list -- one to four blocks, the usual case -- still lands on every XCD and CU.  (With x = list-block row
+    // only rows 0..3 of 32 had work, i.e. XCDs 0..3: 970 targets took as long as 7,700, profiles/r4.)
+    if (LIST) { by = blockIdx.x; bx = blockIdx.y; } else xcd_tile(bx, by);
     const float* __restrict__ tp = a.pos_all + (size_t)a.tgt_chunk * D * a.pad;
     unsigned n_listed = 0u, out_stride = 0u, tiles_per_split = a.tiles_per_split;
     if (LIST) {
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_f64_kernel(KArgs a) {
     }
     const unsigned nblk = LIST ? (n_listed + 256u * TPL - 1u) / (256u * TPL) : bx + 1u;
 
-    for (unsigned tb = bx; tb < nblk; tb += LIST ? gridDim.x : nblk) {
+    for (unsigned tb = bx; tb < nblk; tb += LIST ? gridDim.y : nblk) {
         unsigned idx[TPL];
         double ix[TPL], iy[TPL], iz[TPL], ox[TPL], oy[TPL], oz[TPL], om[MAG ? TPL : 1];
         const unsigned slot0 = tb * (256u * TPL) + tid;   // list slot (LIST) or target index of this lane's q-th target: slot0 + 256 q

@@ -194,10 +194,11 @@ hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
     hipLaunchKernelGGL(table().ck.refine_select[di], dim3((a.count + 255u) / 256u, 1, 1), block, 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // listed targets x strict slices; a workgroup whose list block does not exist returns at once
-    // grid.x = list blocks taken in turn by a row of workgroups: a short list (the usual case) needs one or two, and rows of
-    // idle workgroups cost a scalar load each; 32 x 256 workgroups of one target per lane fill the chip for a long one
+    // grid = (source slices, rows of list blocks): a row's workgroups take list blocks row, row + 32, ...; a short list (the usual
+    // case) needs one to four rows, the idle rows cost a scalar load per workgroup; 256 x 32 workgroups of one target per lane fill the
+    // chip for a long one.  Slices along x: see accel_f64_kernel
     const unsigned list_blocks = (a.count + 255u) / 256u;
-    hipLaunchKernelGGL(table().ck.strict_list[di], dim3(list_blocks < 32u ? list_blocks : 32u, (unsigned)R.strict_slices, 1), block, 0, stream, a);
+    hipLaunchKernelGGL(table().ck.strict_list[di], dim3((unsigned)R.strict_slices, list_blocks < 32u ? list_blocks : 32u, 1), block, 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(table().ck.refine_fold[di], dim3(64, 1, 1), block, 0, stream, a);
     return hipGetLastError();

@@ -47,6 +47,10 @@
 using namespace nbx;
 using namespace nbx_leaf;
 
+#ifndef NBX_LEAF_PACK
+#define NBX_LEAF_PACK 1   /* 0: A/B build without packed small leaves (make LEAF_DEFS=-DNBX_LEAF_PACK=0 ...) */
+#endif
+
 namespace {
 
 constexpr int kUnitsPerLane = 4;               // 16-byte units (= bodies) a lane stages per tile (the kernel names that many registers)
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(64) void leaf_pack_kernel(LeafPackArgs a) {
     __shared__ double osum[3][64];
     const unsigned lane = threadIdx.x;
     const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
-    const uint32_t w = bp->w, P = bp->P, n_sub = bp->n_sub, tiles = bp->tiles, sub_lo = bp->sub_lo;   // wave-uniform
-    const unsigned sub = lane / w, lw = lane - sub * w;            // w is 8 or 16
+    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, tiles = bp->tiles, sub_lo = bp->sub_lo;   // wave-uniform
+    const unsigned sub = lane >> wl, lw = lane & (w - 1u);         // w = 1 << wl is 8 or 16
     const unsigned R = (unsigned)kPackUnitsPerLane * w;            // units of one leaf's tile
     PackSub my = PackSub{0u, 0u, 0u, 0u};
     if (sub < n_sub) my = a.subs[sub_lo + sub];
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64) void leaf_pack_kernel(LeafPackArgs a) {
     const bool odd_unit = (lw & 1u) != 0u;
     const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
     const float4 pad_unit = make_float4(pad_xy, pad_xy, pad_zm, pad_zm);
-    for (unsigned k = lw; k < (unsigned)kPackPadUnits + (sub + 1u == 64u / w ? 16u : 0u); k += w) region[R + k] = pad_unit;   // written once: staging never touches them
+    for (unsigned k = lw; k < (unsigned)kPackPadUnits + (sub + 1u == (64u >> wl) ? 16u : 0u); k += w) region[R + k] = pad_unit;   // written once: staging never touches them
     Sums<D> S;
     osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
     S.o = &osum[0][lane];
@@ -713,7 +717,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
 
     // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
     static thread_local LeafPlan plan;   // a tree code calls once per step: the arrays keep their capacity (and their pages) between calls
-    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan)) return fail(NBX_ERR_INVALID, why);
+    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan, NBX_LEAF_PACK != 0)) return fail(NBX_ERR_INVALID, why);
     const size_t pslots = plan.pslots();
     const std::vector<uint32_t>& pslot_body = plan.pslot_body;
     const std::vector<CopyOp>& ops = plan.ops;
@@ -875,7 +879,7 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     if (rc != NBX_OK) return rc;
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
     LeafPlan host;
-    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host)) return fail(NBX_ERR_INVALID, why);
+    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host, NBX_LEAF_PACK != 0)) return fail(NBX_ERR_INVALID, why);
     nbx_leaf_plan* p = new (std::nothrow) nbx_leaf_plan();
     if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
     p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;

@@ -26,11 +26,16 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // A leaf of a few bodies cannot fill a wave: at 4 bodies per leaf a workgroup's start-up, staging and closing reduction cost ten
 // times its pair arithmetic (0.06 of the fp32 peak in round 3).  Leaves of up to kPackMaxTargets bodies whose list is at most
 // kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 8 or 16 lanes --
-// its own copy runs, its own region of the LDS tile, P = floor(w / bodies) lanes per target (the block's smallest, so that every
-// lane of the wave runs the same trip count) -- and all of them run the pair loop together.  Everything else (larger leaves,
+// its own copy runs, its own region of the LDS tile, P lanes per target (the same for every leaf of the wave -- leaves are packed
+// with leaves of their size class -- so that every lane runs the same trip count) -- and all of them run the pair loop together.  Everything else (larger leaves,
 // longer lists) keeps the one-leaf workgroups above.
 constexpr int kPackMaxTargets = 16;
 constexpr int kPackMaxOps = 16;
+// Packing is used for structures whose leaves hold at most this many bodies ON AVERAGE.  Measured at N = 2^20
+// (profiles/r4/leaf_pack_ab.txt, same box, back-to-back launches): 4-body grid leaves 0.226 -> 0.213 ms packed; median-split
+// leaves of 8 bodies 0.146 -> 0.203 ms and of 16 bodies 0.200 -> 0.273 ms (a leaf of 8-16 bodies fills a wave of its own at
+// 4-8 lanes per target; side by side on 8-16 lanes each they run one lane per target and a quarter of the waves).
+constexpr int kPackMeanLeaf = 6;
 constexpr int kPackUnitsPerLane = 8;           // a sub-leaf's tile is 8 w units: 64 (w = 8) or 128 (w = 16) bodies
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -40,7 +45,8 @@ struct PackBlock {                             // one wave64; read with scalar l
     uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
     uint32_t w, P;                             // lanes per leaf (8 | 16), lanes per target (1 .. 8)
     uint32_t tiles;                            // tile iterations: ceil(longest stream / (kPackUnitsPerLane * w))
-    uint32_t pad_[3];
+    uint32_t w_log2;                           // 3 | 4
+    uint32_t pad_[2];
 };
 static_assert(sizeof(PackSub) == 16 && sizeof(PackBlock) == 32, "read with vector / scalar loads");
 
@@ -153,47 +159,50 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     std::vector<LeafBlock>& blocks = plan.blocks;
     blocks.clear();
     blocks.reserve(n_leaves);
-    // packed waves: consecutive small leaves, greedily -- a leaf joins the open wave if the wave's lane width (the next power of
-    // two >= its largest leaf, at least 8) still leaves room for one more leaf
+    {
+        size_t nonempty_leaves = 0;
+        for (size_t l = 0; l < n_leaves; ++l) nonempty_leaves += leaf_offsets[l + 1] > leaf_offsets[l];
+        pack_small_leaves = pack_small_leaves && nonempty_leaves && slots <= (size_t)kPackMeanLeaf * nonempty_leaves;
+    }
+    // packed waves.  Leaves are packed with leaves of their own SIZE CLASS -- 1, 2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2, 1
+    // lanes per target), 9-16 bodies on 16 lanes -- in leaf order within the class, so that every wave runs the most lanes per
+    // target its leaves allow (mixed, one 8-body leaf would hold seven smaller ones at one lane per target).
     std::vector<PackSub>& subs = plan.pack_subs;
     std::vector<PackBlock>& packs = plan.pack_blocks;
     subs.clear();
     packs.clear();
-    uint32_t open_w = 0, open_cmax = 0, open_stream = 0;   // the open wave: lane width, largest leaf, longest stream (units)
-    auto close_pack = [&]() {
-        if (!open_w) return;
-        PackBlock& b = packs.back();
-        b.w = open_w;
-        uint32_t P = open_w / open_cmax;
-        b.P = P > (uint32_t)kMaxLanesPerTarget ? (uint32_t)kMaxLanesPerTarget : P;
-        const uint32_t tile_units = (uint32_t)kPackUnitsPerLane * open_w;
-        b.tiles = (open_stream + tile_units - 1u) / tile_units;
-        open_w = 0;
-    };
+    auto size_class = [](uint32_t c) -> int { return c <= 1u ? 0 : c <= 2u ? 1 : c <= 4u ? 2 : c <= 8u ? 3 : 4; };
+    std::vector<uint32_t> packable[5];
+    for (size_t l = 0; l < n_leaves; ++l) {
+        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
+        if (pack_small_leaves && c >= 1u && c <= (uint32_t)kPackMaxTargets && op_off[l + 1] - op_off[l] <= (uint32_t)kPackMaxOps)
+            packable[size_class(c)].push_back((uint32_t)l);
+    }
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t w = k == 4 ? 16u : 8u, per_wave = 64u / w;
+        const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : k == 2 ? 2u : 1u;
+        for (size_t i = 0; i < packable[k].size(); i += per_wave) {
+            PackBlock b{};
+            b.sub_lo = (uint32_t)subs.size();
+            b.w = w; b.w_log2 = k == 4 ? 4u : 3u; b.P = P;
+            uint32_t longest = 0;
+            for (size_t j = i; j < packable[k].size() && j < i + per_wave; ++j) {
+                const uint32_t l = packable[k][j];
+                const uint32_t n_ops = op_off[l + 1] - op_off[l];
+                const uint32_t stream = n_ops ? ops[op_off[l] + n_ops - 1].end : 0u;
+                subs.push_back(PackSub{op_off[l], n_ops, unit_off[l], leaf_offsets[l + 1] - leaf_offsets[l]});
+                ++b.n_sub;
+                if (stream > longest) longest = stream;
+            }
+            const uint32_t tile_units = (uint32_t)kPackUnitsPerLane * w;
+            b.tiles = (longest + tile_units - 1u) / tile_units;
+            packs.push_back(b);
+        }
+    }
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (!c) continue;
-        const uint32_t n_ops = op_off[l + 1] - op_off[l];
-        if (pack_small_leaves && c <= (uint32_t)kPackMaxTargets && n_ops <= (uint32_t)kPackMaxOps) {
-            const uint32_t need_w = c <= 8u ? 8u : 16u;
-            const uint32_t stream = n_ops ? ops[op_off[l] + n_ops - 1].end : 0u;
-            if (open_w) {
-                const uint32_t w2 = open_w > need_w ? open_w : need_w;
-                if (packs.back().n_sub + 1u <= 64u / w2) open_w = w2;
-                else close_pack();
-            }
-            if (!open_w) {
-                PackBlock b{};
-                b.sub_lo = (uint32_t)subs.size();
-                packs.push_back(b);
-                open_w = need_w; open_cmax = 0; open_stream = 0;
-            }
-            subs.push_back(PackSub{op_off[l], n_ops, unit_off[l], c});
-            ++packs.back().n_sub;
-            if (c > open_cmax) open_cmax = c;
-            if (stream > open_stream) open_stream = stream;
-            continue;
-        }
+        if (pack_small_leaves && c <= (uint32_t)kPackMaxTargets && op_off[l + 1] - op_off[l] <= (uint32_t)kPackMaxOps) continue;   // packed above
         const uint32_t groups = (c + per_group - 1u) / per_group;
         uint32_t f = unit_off[l];
         for (uint32_t gi = 0; gi < groups; ++gi) {
@@ -215,7 +224,6 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             f += share;
         }
     }
-    close_pack();
     if (packs.size() > 1) {   // longest first, stable (leaf order kept among waves of equal length)
         std::vector<PackBlock> sorted(packs);
         uint32_t longest = 0;

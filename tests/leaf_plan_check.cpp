@@ -41,6 +41,6 @@ int main(int argc, char** argv) {
     static_assert(sizeof(nbx_leaf::PackSub) == 16 && sizeof(nbx_leaf::PackBlock) == 32, "written as raw words");
     store(d + "pack_subs.u32", plan.pack_subs.data(), plan.pack_subs.size() * 16);
     store(d + "pack_blocks.u32", plan.pack_blocks.data(), plan.pack_blocks.size() * 32);
-    printf("waves %d blocks %zu ops %zu pslots %zu\n", plan.waves, plan.blocks.size(), plan.ops.size(), plan.pslots());
+    printf("waves %d blocks %zu ops %zu pslots %zu packs %zu\n", plan.waves, plan.blocks.size(), plan.ops.size(), plan.pslots(), plan.pack_blocks.size());
     return 0;
 }

@@ -52,6 +52,11 @@ def _structure(seed, sizes, list_len):
     return lo, lb, so, ss
 
 
+def packs_w_log2(plan, sub_lo):
+    rows = plan["pack_blocks"]
+    return int(rows[rows[:, 0] == sub_lo][0, 5])
+
+
 def n_ops_of_leaf(op_off, l):
     return int(op_off[l + 1]) - int(op_off[l])
 
@@ -89,7 +94,7 @@ def _check(plan, lo, lb, so, ss):
     for op_lo, op_n, key, _, f0, c0, f1, c1 in blocks.astype(np.int64):
         assert c0 <= 64 and c1 <= 64 and c0 + c1 >= 1 and (waves == 2 or c1 == 0)
         l = leaf_of_unit[f0 if c0 else f1]
-        assert sizes[l] > 16 or n_ops_of_leaf(op_off, l) > 16   # small leaves with short lists are packed, not here
+        assert sizes[l] > 16 or n_ops_of_leaf(op_off, l) > 16 or not (nonempty.sum() <= 6 * nonempty.size)   # tiny-leaf structures pack those
         assert op_lo == op_off[l] and op_n == op_off[l + 1] - op_off[l]
         for f, c in ((f0, c0), (f1, c1)):
             if c:
@@ -106,8 +111,11 @@ def _check(plan, lo, lb, so, ss):
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
         assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 16).all()
-        assert P == min(8, w // mine[:, 3].max())
-        assert w == (8 if mine[:, 3].max() <= 8 else 16) or n_sub == 1 or w == 16
+        # leaves share a wave with leaves of their size class: 1, 2, 3-4, 5-8 bodies on 8 lanes (8, 4, 2, 1 lanes per target), 9-16 on 16
+        cls = lambda c: 0 if c <= 1 else 1 if c <= 2 else 2 if c <= 4 else 3 if c <= 8 else 4
+        k = cls(mine[0, 3])
+        assert all(cls(c) == k for c in mine[:, 3]) and w == (16 if k == 4 else 8) and P == (8, 4, 2, 1, 1)[k]
+        assert (mine[:, 3] * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
         streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
         assert tiles == -(-max(streams) // int(8 * w))
         for o, k, f, c in mine:
@@ -118,10 +126,11 @@ def _check(plan, lo, lb, so, ss):
     assert (seen_sub == 1).all()
     if packs.shape[0] > 1:
         assert (np.diff(packs[:, 4]) <= 0).all()                # longest first
-    # a leaf is packed exactly when it is small and its list short
+    # a leaf is packed exactly when the structure's leaves are tiny on average (<= 6 bodies), it is small and its list short
     packed_leaves = set(leaf_of_unit[subs[:, 2]].tolist()) if subs.shape[0] else set()
+    tiny = bool(nonempty.size) and nonempty.sum() <= 6 * nonempty.size
     for l in range(sizes.size):
-        assert (l in packed_leaves) == (1 <= sizes[l] <= 16 and n_ops_of[l] <= 16), l
+        assert (l in packed_leaves) == bool(tiny and 1 <= sizes[l] <= 16 and n_ops_of[l] <= 16), l
     assert (hit == (pslot_body != PAD)).all()
     # launch order: longest first (1024 duration classes)
     key = blocks[:, 2].astype(np.int64)
@@ -138,6 +147,8 @@ def test_plan_of_ragged_structures(planner, tmp_path):
         (3, list(range(1, 25)) * 3 + [30, 27], lambda t: 9),                                           # small leaves: one wave per workgroup
         (4, [0, 0, 0], lambda t: 2),                                                                   # nothing but empty leaves
         (5, [64, 128, 129, 1, 65], lambda t: 5),
+        (6, [4, 3, 5, 0, 1, 2, 8, 9, 16, 7, 4, 4, 6, 2, 1, 3] * 9 + [40], lambda t: [3, 9, 27, 17][t % 4]),            # tiny leaves: packed by size class
+        (7, [1, 2, 3, 4] * 20, lambda t: 2),
     ]
     merged = 0
     for seed, sizes, list_len in cases:
