@@ -200,7 +200,7 @@ hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
     const unsigned list_blocks = (a.count + 255u) / 256u;
     hipLaunchKernelGGL(table().ck.strict_list[di], dim3((unsigned)R.strict_slices, list_blocks < 32u ? list_blocks : 32u, 1), block, 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(table().ck.refine_fold[di], dim3(64, 1, 1), block, 0, stream, a);
+    hipLaunchKernelGGL(table().ck.refine_fold[di], dim3(512, 1, 1), block, 0, stream, a);   // 2,048 waves, one (target, component) each per turn
     return hipGetLastError();
 }
 
