@@ -69,7 +69,8 @@ int nbx_device_count(int* count);
  * that times whole calls, like the reference's safely_execute (utils.h:87-104), does not charge it to the
  * first solver call -- the way OpenMP's thread pool is already up when the reference times its CPU rows. */
 int nbx_warmup(int device);
-/* The library keeps a few idle HIP streams per device, the RCCL communicators of destroyed nodes, and the device allocation of
+/* The library keeps a few idle HIP streams per device, the RCCL communicators of destroyed nodes, the device allocations of the last
+ * two destroyed contexts per device (up to 64 MiB each), and the device allocation of
  * the last nbx_leaf_pair_forces call per device (up to 2 GiB), for the next
  * context / node / call on the same devices (creating a stream costs ~1.4 ms and destroying one up to 3 ms on this runtime,
  * a communicator set for 8 GPUs far more -- against a force evaluation of 0.07 ms at N = 1,000).  This gives them

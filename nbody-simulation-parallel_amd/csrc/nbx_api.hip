@@ -69,6 +69,73 @@ void park_stream(int device, hipStream_t s) {   // s is idle: the caller has syn
     (void)hipStreamDestroy(s);
 }
 
+// The same for a context's device allocation: hipFree of a few MB costs 0.2 ms on this runtime, hipMalloc not much less, and the
+// drop-in call makes and destroys a context per call -- at N = 1,000 that was half of the call.  A destroyed context parks its
+// arena (up to kArenaParkMaxBytes; two per device); the next context on that device that fits takes it.  Nothing in the library
+// relies on fresh memory being zero (hipMalloc does not promise it either).
+namespace {
+struct ParkedCtxArena { int device; char* p; size_t bytes; };
+std::vector<ParkedCtxArena> g_ctx_arenas;   // under g_stream_pool_mu
+constexpr size_t kArenaParkMaxBytes = (size_t)64 << 20;
+constexpr size_t kArenasParkedPerDevice = 2;
+}  // namespace
+
+hipError_t take_ctx_arena(int device, size_t bytes, char** out, size_t* got) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        size_t best = g_ctx_arenas.size();
+        for (size_t i = 0; i < g_ctx_arenas.size(); ++i)
+            if (g_ctx_arenas[i].device == device && g_ctx_arenas[i].bytes >= bytes && g_ctx_arenas[i].bytes <= 4 * bytes + (1u << 20) &&
+                (best == g_ctx_arenas.size() || g_ctx_arenas[i].bytes < g_ctx_arenas[best].bytes)) best = i;
+        if (best != g_ctx_arenas.size()) {
+            *out = g_ctx_arenas[best].p;
+            *got = g_ctx_arenas[best].bytes;
+            g_ctx_arenas.erase(g_ctx_arenas.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    *got = bytes;
+    void* a = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipErrorOutOfMemory) {   // parked allocations (here and in the leaf path) may be what is in the way
+        (void)hipGetLastError();
+        release_parked_ctx_arenas();
+        release_parked_leaf_arenas();
+        e = hipMalloc(&a, bytes);
+    }
+    *out = static_cast<char*>(a);
+    return e;
+}
+
+void park_ctx_arena(int device, char* p, size_t bytes) {   // nothing on the device uses p any more
+    char* evicted = nullptr;
+    if (bytes <= kArenaParkMaxBytes) {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        g_ctx_arenas.push_back(ParkedCtxArena{device, p, bytes});
+        size_t mine = 0, oldest = g_ctx_arenas.size();
+        for (size_t i = 0; i < g_ctx_arenas.size(); ++i)
+            if (g_ctx_arenas[i].device == device) { if (oldest == g_ctx_arenas.size()) oldest = i; ++mine; }
+        if (mine > kArenasParkedPerDevice) { evicted = g_ctx_arenas[oldest].p; g_ctx_arenas.erase(g_ctx_arenas.begin() + (long)oldest); }
+    } else {
+        evicted = p;
+    }
+    if (evicted) (void)hipFree(evicted);
+}
+
+void release_parked_ctx_arenas() {
+    std::vector<ParkedCtxArena> parked;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        parked.swap(g_ctx_arenas);
+    }
+    int before = 0;
+    const bool have = hipGetDevice(&before) == hipSuccess;
+    for (auto& e : parked)
+        if (hipSetDevice(e.device) == hipSuccess) (void)hipFree(e.p);
+    if (have) (void)hipSetDevice(before);
+    (void)hipGetLastError();
+}
+
 void release_parked_streams() {
     std::vector<std::pair<int, hipStream_t>> parked;
     {
@@ -510,6 +577,7 @@ double nbx_refine_sigma_default(int dim) { return dim == 2 ? kRefineSigmaDefault
 int nbx_release_cached(void) {
     release_parked_communicators();
     release_parked_leaf_arenas();
+    release_parked_ctx_arenas();
     release_parked_streams();
     return NBX_OK;
 }
@@ -588,10 +656,7 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
             want += arena_round((size_t)splits * variant_planes(c->variant) * pad * sizeof(float)) + arena_round(list_bytes) + arena_round(acc_bytes);
         }
         if (want <= ((size_t)64 << 30)) {   // beyond that the pieces are allocated one by one, and fail one by one
-            void* a = nullptr;
-            CTX_TRY(hipMalloc(&a, want));
-            c->arena = static_cast<char*>(a);
-            c->arena_bytes = want;
+            CTX_TRY(take_ctx_arena(device, want, &c->arena, &c->arena_bytes));   // a parked one of a destroyed context, or a fresh one
         }
     }
 #define CTX_ALLOC(ptr, bytes) do { int r_ = dev_alloc(c, &(ptr), (bytes)); if (r_) { nbx_ctx_destroy(c); return r_; } } while (0)
@@ -614,7 +679,11 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->extra) (void)hipFree(p);   // every device buffer is a piece of the arena or one of these
-    if (c->arena) (void)hipFree(c->arena);
+    if (c->arena) {   // the stream(s) were synchronised above: nothing on the device uses it any more
+        const bool idle = (!c->stream || hipStreamSynchronize(c->stream) == hipSuccess) && (!c->own_stream || hipStreamSynchronize(c->own_stream) == hipSuccess);
+        if (idle) park_ctx_arena(c->device, c->arena, c->arena_bytes);
+        else (void)hipFree(c->arena);
+    }
     if (c->counters_host) (void)hipHostFree(c->counters_host);
     if (c->counters_ev) (void)hipEventDestroy(c->counters_ev);
     if (c->step_exec) (void)hipGraphExecDestroy(c->step_exec);

@@ -108,6 +108,10 @@ int fail(int code, const char* msg);
 hipError_t take_stream(int device, hipStream_t* out);
 void park_stream(int device, hipStream_t s);
 void release_parked_streams();
+// a destroyed context's device allocation is kept for the next context on that device (nbx_api.hip)
+hipError_t take_ctx_arena(int device, size_t bytes, char** out, size_t* got);
+void park_ctx_arena(int device, char* p, size_t bytes);
+void release_parked_ctx_arenas();
 // the two halves of nbx_ctx_upload_bodies (nbx_api.hip), apart so that the node layer can upload each rank's own shard
 // only and fill the other chunks device to device in between
 int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3],

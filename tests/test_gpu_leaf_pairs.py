@@ -312,7 +312,8 @@ def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
         warm = plan.time_kernel(nbx.LAW_TREE_LEAF, 300)
         print(f"\nplan: evaluation of the unchanged structure from resident bodies: wall median {np.median(walls):.3f} ms (min {min(walls):.3f}), "
               f"pair kernel {one:.3f} ms single launch, {warm:.3f} ms mean of launches 151-300; slots/runs/workgroups/waves {plan.info()}")
-        assert np.median(walls) <= 0.6, f"second call on an unchanged structure took {np.median(walls):.3f} ms (one-shot call: 3.2 ms)"
+        # measured 0.38-0.47 ms over the round's boxes (profiles/r4); the bound leaves room for a loaded box, the one-shot call takes 3.2 ms
+        assert np.median(walls) <= 0.8, f"an evaluation of an unchanged structure took {np.median(walls):.3f} ms"
     lo, _, so, ss = leaves
     sizes = np.diff(lo).astype(np.int64)
     pairs = int(sum(sizes[t] * sizes[ss[so[t]:so[t + 1]]].sum() for t in range(sizes.size)))

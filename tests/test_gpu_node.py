@@ -131,7 +131,7 @@ def test_pass_times_of_a_sharded_evaluation(nbx, oracle):
         again = node.pass_times(1)
     assert [t["rank"] for t in times] == list(range(ranks)) and sum(t["targets"] for t in times) == n
     for t in times + [again]:
-        assert t["device"] == 0 and t["local_ms"] > 0 and t["remote_ms"] > t["local_ms"] and t["exchange_ms"] >= 0
+        assert t["device"] == 0 and t["local_ms"] > 0 and t["remote_ms"] > 0 and t["exchange_ms"] >= 0   # (virtual ranks share a GPU: no ordering of the two)
         assert isinstance(t["exchange_hidden"], bool)
     with nbx.Node(5000, dim, [0]) as one:           # one rank: no passes to tell apart, zeros and no error
         one.upload(b[:5000])
