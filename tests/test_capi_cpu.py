@@ -141,3 +141,52 @@ def test_leaf_pair_entry_validates_before_it_needs_a_device(nbx):
         with pytest.raises(nbx.NbxError) as e:
             nbx.leaf_pair_forces_hip(b, *ok)
         assert e.value.status in (2, 3) and "no CPU fallback" in str(e.value)          # NO_DEVICE / HIP
+
+
+def test_new_entry_points_validate_and_fail_loudly_without_a_device(nbx):
+    """ABI 4's additions: the process-wide precision default needs no device; the leaf plan validates its CSR arrays on the host
+    before it asks for a device; every plan / node / context entry rejects a null handle; without a GPU a well-formed plan is
+    NO_DEVICE (no CPU fallback)."""
+    lib = nbx.load_library()
+    assert nbx.get_default_refine() == (1e-5, 0.0)
+    try:
+        nbx.set_default_refine(1e-6, 12.0)
+        assert nbx.get_default_refine() == (1e-6, 12.0)
+        for bad in ((1e-9, 0.0), (0.1, 0.0), (1e-5, -1.0), (float("nan"), 0.0)):
+            with pytest.raises(nbx.NbxError) as e:
+                nbx.set_default_refine(*bad)
+            assert e.value.status == 1
+        assert nbx.get_default_refine() == (1e-6, 12.0)           # a refused call changes nothing
+    finally:
+        nbx.set_default_refine(1e-5, 0.0)
+    assert lib.nbx_refine_sigma_default(3) > 0 and lib.nbx_refine_sigma_default(2) >= lib.nbx_refine_sigma_default(3)
+    ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
+    bad = [
+        (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 2])),            # source leaf out of range
+        (np.array([0, 5, 10]), np.r_[np.arange(9), 0], np.array([0, 1, 2]), np.array([0, 1])),   # body in two leaves
+        (np.array([1, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1])),            # offsets not from 0
+    ]
+    for leaves in bad:
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.LeafPlan(10, 3, *leaves)
+        assert e.value.status == 1
+    with pytest.raises(nbx.NbxError) as e:
+        nbx.LeafPlan(10, 4, *ok)                                  # dim
+    assert e.value.status == 1
+    if _no_gpu(nbx):
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.LeafPlan(10, 3, *ok)
+        assert e.value.status in (2, 3) and "no CPU fallback" in str(e.value)
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.brute_force_hip_n_body(np.zeros((4, 7)), rel_tolerance=0.0)
+        assert e.value.status == 2
+    z = ctypes.c_float(0.0)
+    for fn, args in ((lib.nbx_leaf_plan_forces, (None, None, 56, 1, 1.0, None, None)), (lib.nbx_leaf_plan_forces_ctx, (None, None, 1, 1.0, None, None)),
+                     (lib.nbx_leaf_plan_get_forces, (None, None)), (lib.nbx_leaf_plan_kick_drift, (None, None, 1.0)),
+                     (lib.nbx_leaf_plan_time_kernel, (None, 1, 3, ctypes.byref(z))), (lib.nbx_leaf_plan_info, (None, None, None, None, None)),
+                     (lib.nbx_ctx_upload_shard, (None, None, 56, None, None)), (lib.nbx_ctx_upload_finish, (None, 1.0, 1.0)),
+                     (lib.nbx_ctx_refine_time, (None, ctypes.byref(z))), (lib.nbx_node_refine_stats, (None, None, None)),
+                     (lib.nbx_node_enable_timing, (None, 1)), (lib.nbx_node_pass_times, (None, 0, None, None, None, None, None, None))):
+        assert fn(*args) == 1, fn
+    assert lib.nbx_leaf_plan_destroy(None) == 0
+    assert lib.nbx_brute_force_forces_ex(None, 4, 3, 56, 1.0, 0, -1.0, None, None) == 1
