@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 // REGSUMS = 1: the fp64 slice sums stay in registers instead (48 more VGPRs: two waves per SIMD -- the two-level kernel loses
 // 0.4 % at that occupancy, profiles/r2/variants_shape.txt); with WAVES = 2 the source tile is double-buffered again (one barrier
 // per tile), with WAVES = 3 the 52 KB of LDS per workgroup leave room for a single tile buffer only (two barriers per tile).
-template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS, int REGSUMS>
+template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS, int REGSUMS, int PEEL = 1>
 __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
     constexpr int NBUF = WAVES <= 2 ? 2 : 1;
@@ -615,24 +615,35 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
         for (int blk = 0; blk < kTile / LB; ++blk) {
             f2 ax[PAIRS], ay[PAIRS], az[PAIRS];
             const float4* __restrict__ cur = tile + buf * kTile + blk * LB;
-            {   // the block's first source starts the sums (no zeroing)
+            if (PEEL) {   // the block's first source starts the sums (no zeroing)
                 const float4 s = cur[0];
                 interact2_staged<D, PAIRS, 0, 0, 1, 1>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) ax[q] = ay[q] = az[q] = f2{0.f, 0.f};
             }
 #pragma unroll UNROLL
-            for (int j = 1; j < LB; ++j) {
+            for (int j = PEEL ? 1 : 0; j < LB; ++j) {
                 const float4 s = cur[j];
                 interact2_staged<D, PAIRS, 0, 0, 1>(s.x, s.y, s.z, f2{s.z, s.w}, ix, iy, iz, ax, ay, az, bias);
             }
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q) { ox[q] += ax[q]; oy[q] += ay[q]; if (D == 3) oz[q] += az[q]; }
-            if (QS) {
+            if (QS == 1) {
 #pragma unroll
                 for (int q = 0; q < PAIRS; ++q) {
                     qq[q] = __builtin_elementwise_fma(ax[q], ax[q], qq[q]);
                     qq[q] = __builtin_elementwise_fma(ay[q], ay[q], qq[q]);
                     if (D == 3) qq[q] = __builtin_elementwise_fma(az[q], az[q], qq[q]);
                 }
+            }
+        }
+        if (QS == 2) {   // A/B: the spread from the TILE sums, like the two-level kernel's (a quarter of the instructions)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                qq[q] = __builtin_elementwise_fma(ox[q], ox[q], qq[q]);
+                qq[q] = __builtin_elementwise_fma(oy[q], oy[q], qq[q]);
+                if (D == 3) qq[q] = __builtin_elementwise_fma(oz[q], oz[q], qq[q]);
             }
         }
         // level 3: the tile's sums into the lane's own fp64 slots
@@ -1016,6 +1027,11 @@ const KernelVariant kVariants[] = {
     {"fastpk3lr_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 1)},  // two waves per SIMD: double-buffered tiles, fp64 slice sums in registers
     {"fastpk3lr32_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 32, 1)},// the same with 32-source blocks
     {"fastpk3l32_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 32, 0)}, // 32-source blocks: errors another 1.2x smaller, +1.1 % time
+    {"fastpk3l_t8_w3_u4_nopeel", 8, accel_fast3l_kernel<2, 4, 3, 4, 64, 0, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 0, 0, 0>, 1, 0, 0, nullptr, nullptr, nullptr, nullptr,
+     accel_fast3l_kernel<2, 4, 3, 4, 64, 1, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 1, 0, 0>, 2, 0},   // block sums zeroed instead of started by the first source
+    {"fastpk3l_t8_w3_u4_qtile", 8, accel_fast3l_kernel<2, 4, 3, 4, 64, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 0, 0>, 1, 0, 0, nullptr, nullptr, nullptr, nullptr,
+     accel_fast3l_kernel<2, 4, 3, 4, 64, 2, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 2, 0>, 2, 0},         // Q from the tile sums instead of the block sums
+    {"fastpk3l128_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 128, 0)},   // 128-source blocks: half the block flushes, errors 1.4x larger
 #endif
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
 #ifdef NBX_AB_HI_SEL

@@ -307,7 +307,7 @@ int slices_for(const nbx_ctx* c, int variant) {
 
 // Mixed mode's fp64 pass: a list with room for EVERY target of the shard, and sums for up to 256 source slices of a list of
 // typical length (1/64 of the shard: the rule lists well under a percent of uniform or Plummer 3D bodies, a few percent in
-// 2D) -- at least the whole shard in one slice.  The device picks slices x stride within this budget from the list's actual
+// 2D) -- at least the whole shard in eight slices (201 MB at N = 2^20).  The device picks slices x stride within this budget from the list's actual
 // length (force_kernel.hip strict_layout): a long list costs time, never accuracy.
 void strict_sizes(nbx_ctx* c, size_t* list_bytes, size_t* acc_bytes) {
     c->strict_cap = c->pad;
@@ -316,7 +316,8 @@ void strict_sizes(nbx_ctx* c, size_t* list_bytes, size_t* acc_bytes) {
     size_t typical = ((size_t)c->pad / 64 + 255) / 256 * 256;
     if (typical < 256) typical = 256;
     size_t per_comp = typical * (size_t)c->strict_slices;
-    if (per_comp < c->pad) per_comp = c->pad;
+    const size_t whole = (size_t)c->pad * (c->strict_slices < 8 ? (size_t)c->strict_slices : 8);   // every target listed: still 8 slices x 32 rows of workgroups
+    if (per_comp < whole) per_comp = whole;
     c->strict_budget = (unsigned long long)c->dim * per_comp;
     *list_bytes = (size_t)c->strict_cap * sizeof(unsigned);
     *acc_bytes = (size_t)c->strict_budget * sizeof(double);
