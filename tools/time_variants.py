@@ -19,12 +19,21 @@ with nbx.Context(n, 3) as c:
         c.set_refine(0.0)
     print("precision:", "plain fp32" if os.environ.get("NBX_TIME_PLAIN") else "mixed mode (spread-sum builds)", flush=True)
     res = {v: [] for v in sel}
+    forces = {}
     for r in range(rounds + 1):
         for v in sel:
             c.set_tuning(0, v)
             c.compute_accel()
             ms, _ = c.kernel_time()
             if r: res[v].append(ms)
+            elif os.environ.get("NBX_TIME_COMPARE"):
+                forces[v] = c.forces()
+    if forces:   # NBX_TIME_COMPARE=1: every variant's forces against the first selected one (builds of one summation must agree bit for bit)
+        first = sel[0]
+        scale = np.abs(forces[first]).max()
+        for v in sel[1:]:
+            d = np.abs(forces[v] - forces[first]).max() / scale
+            print(f"forces of {names[v]} vs {names[first]}: max |dF| / max |F| = {d:.3e}" + ("  (identical)" if d == 0 else ""), flush=True)
     print(f"N={n}  interactions {n*n:.3e}  rounds {rounds}", flush=True)
     for v in sorted(sel, key=lambda v: min(res[v])):
         best, med = min(res[v]), sorted(res[v])[len(res[v]) // 2]
