@@ -1,6 +1,6 @@
 """Measurement / robustness run (GPU box, not part of the suite): random leaf structures through nbx_leaf_pair_forces against the
 oracle -- leaf sizes from empty to several workgroups, lists with repeats, empty and consecutive leaves, streams of several tiles,
-bodies in no leaf, small and large coordinate boxes (guarded and unguarded waves, and both in one launch), masses above and below the
+bodies in no leaf, structures of tiny leaves (packed several to a wave), small and large coordinate boxes (guarded and unguarded waves, and both in one launch), masses above and below the
 bound of the unguarded loop, planted identical positions; both dimensions, all three laws.
     python tests/measure/leaf_fuzz.py [cases] [seed]"""
 import os
@@ -17,10 +17,13 @@ from oracle_lib import Oracle, assert_force_parity  # noqa: E402
 
 def one_case(rng, oracle, k):
     dim = int(rng.choice([2, 3]))
-    regime = rng.choice(["small", "medium", "big", "mixed"])
-    n_leaves = int(rng.integers(1, 40))
-    hi = {"small": 20, "medium": 80, "big": 300, "mixed": 200}[regime]
+    regime = rng.choice(["tiny", "small", "medium", "big", "mixed"])
+    # tiny: a few bodies per leaf and many leaves -- the structures the planner PACKS, several leaves to a wave (mean leaf <= 6)
+    n_leaves = int(rng.integers(1, 300)) if regime == "tiny" else int(rng.integers(1, 40))
+    hi = {"tiny": int(rng.integers(2, 11)), "small": 20, "medium": 80, "big": 300, "mixed": 200}[regime]
     sizes = rng.integers(0, hi, n_leaves)
+    if regime == "tiny" and rng.random() < 0.3:
+        sizes[int(rng.integers(0, n_leaves))] = int(rng.integers(11, 40))   # one larger leaf among them (its own workgroup, or the 9-16 class)
     if regime == "mixed":
         sizes[rng.random(n_leaves) < 0.6] //= 16
     sizes[rng.random(n_leaves) < 0.1] = 0
