@@ -166,7 +166,8 @@ int nbx_leaf_plan_forces(nbx_leaf_plan* plan, const void* bodies, size_t body_st
  * nbx_leaf_plan_kick_drift and the call does not wait for the device (kernel_ms must be NULL too).  With forces_out or
  * kernel_ms the call synchronises the stream. */
 int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* plan, nbx_ctx* ctx, int law, double G, double* forces_out, float* kernel_ms);
-/* Forces of the last evaluation (n_bodies x Vector<dim>) -- F = +-(G m_i) x the leaf sums, the law's sign.  Synchronises. */
+/* Forces of the last evaluation (n_bodies x Vector<dim>) -- F = +-(G m_i) x the leaf sums, the law's sign.  Synchronises.  The masses
+ * are read where that evaluation found them: after nbx_leaf_plan_forces_ctx the context must still exist. */
 int nbx_leaf_plan_get_forces(nbx_leaf_plan* plan, double* forces_out);
 /* update_body_velocities + update_body_positions (methods.cpp:425-450) of `ctx`'s bodies from the LAST evaluation's leaf sums
  * (law and G as given there), fp64, the arithmetic of nbx_ctx_kick_drift; bodies in no leaf drift with their velocity.

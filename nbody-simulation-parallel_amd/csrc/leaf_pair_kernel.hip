@@ -950,7 +950,9 @@ int nbx_leaf_plan_destroy(nbx_leaf_plan* p) {
     if (!p) return NBX_OK;
     DeviceScope scope;
     (void)hipSetDevice(p->device);
-    if (p->last_stream) (void)hipStreamSynchronize(p->last_stream);
+    // the last evaluation may have been queued on a context's stream, and that context may be gone by now (its stream with it):
+    // wait on the plan's own event, which every piece of work queued on a foreign stream is followed by
+    if (p->last_stream && p->done) (void)hipEventSynchronize(p->done);
     bool idle = p->stream && hipStreamSynchronize(p->stream) == hipSuccess;
     if (p->arena) (void)hipFree(p->arena);
     if (p->forces) (void)hipFree(p->forces);
@@ -1044,7 +1046,10 @@ int nbx_leaf_plan_get_forces(nbx_leaf_plan* p, double* forces_out) {
     DeviceScope scope;
     int rc = plan_set_device(p);
     if (rc) return rc;
-    return plan_forces_out(p, p->last_stream, forces_out);
+    // on the plan's own stream, behind the last evaluation's event (the stream that evaluation ran on may belong to a context that no longer exists)
+    if ((rc = plan_order_after_last(p, p->stream))) return rc;
+    if ((rc = plan_forces_out(p, p->stream, forces_out))) return rc;
+    return plan_mark_done(p, p->stream);
 }
 
 int nbx_leaf_plan_kick_drift(nbx_leaf_plan* p, nbx_ctx* c, double dt) {
@@ -1076,7 +1081,8 @@ int nbx_leaf_plan_time_kernel(nbx_leaf_plan* p, int law, int reps, float* mean_m
     DeviceScope scope;
     int rc = plan_set_device(p);
     if (rc) return rc;
-    hipStream_t s = p->last_stream;
+    hipStream_t s = p->stream;   // the plan's own stream, behind the last evaluation (see nbx_leaf_plan_get_forces)
+    if ((rc = plan_order_after_last(p, s))) return rc;
     const int timed_from = reps / 2;
     for (int r = 0; r < reps; ++r) {
         if (r == timed_from) NBX_HIP_TRY(hipEventRecord(p->ev0, s));
@@ -1089,7 +1095,7 @@ int nbx_leaf_plan_time_kernel(nbx_leaf_plan* p, int law, int reps, float* mean_m
     // the sums now belong to `law`: keep the bookkeeping of the last evaluation consistent with them
     p->last_signedG = (law == NBX_LAW_BRUTE) ? -std::fabs(p->last_signedG) : std::fabs(p->last_signedG);
     p->last_law = law;
-    return NBX_OK;
+    return plan_mark_done(p, s);
 }
 
 }  // extern "C"

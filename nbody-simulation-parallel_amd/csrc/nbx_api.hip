@@ -205,9 +205,10 @@ int dev_alloc(nbx_ctx* c, T** p, size_t bytes) {
     }
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
-    if (e == hipErrorOutOfMemory) {   // the leaf path's parked allocations (up to 2 x 2 GiB per device) may be what is in the way
+    if (e == hipErrorOutOfMemory) {   // parked allocations (the leaf path's: up to 2 x 2 GiB per device; destroyed contexts') may be what is in the way
         (void)hipGetLastError();
         release_parked_leaf_arenas();
+        release_parked_ctx_arenas();
         e = hipMalloc(&q, bytes);
     }
     HIP_TRY(e);
