@@ -191,7 +191,7 @@ hipError_t launch_refine(int dim, const RefineLaunch& R, hipStream_t stream) {
     const int di = dim - 2;
     const dim3 block(256, 1, 1);
     if ((e = hipMemsetAsync(a.counters + 3, 0, sizeof(unsigned), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(table().ck.refine_select[di], dim3((a.count + 255u) / 256u, 1, 1), block, 0, stream, a);
+    hipLaunchKernelGGL(table().ck.refine_select[di], dim3((a.count + 63u) / 64u, 1, 1), block, 0, stream, a);   // four lanes per target
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // listed targets x strict slices; a workgroup whose list block does not exist returns at once
     // grid = (source slices, rows of list blocks): a row's workgroups take list blocks row, row + 32, ...; a short list (the usual
