@@ -314,16 +314,18 @@ int nbx_ctx_set_softening(nbx_ctx* ctx, double epsilon);
  * place of v_rcp_f32 and one more multiply.  Forces, kick/drift, energy and the accuracy metric all follow the law. */
 enum { NBX_FORCE_LAW_REFERENCE = 0, NBX_FORCE_LAW_NEWTON = 1 };
 int nbx_ctx_set_law(nbx_ctx* ctx, int law);
-/* PRECISION.  The reference's arithmetic is fp64 throughout (vector.h:9-12, methods.cpp:21-37); the device's default is
- * fp32 pair terms with the stated tolerance of DESIGN.md section 4.  Two ways to go beyond it, both on the reference law:
+/* PRECISION.  The reference's arithmetic is fp64 throughout (vector.h:9-12, methods.cpp:21-37); the device computes pair terms
+ * in fp32 (stated tolerance: DESIGN.md section 4).  Two ways to go beyond plain fp32, both on the reference law -- the second is
+ * what every context starts with (1e-5):
  *  - the variant "strict_f64_t4" (nbx_ctx_set_tuning): EVERY pair term, the skip-rule comparison and every sum in fp64 on
  *    the device's fp32-representable positions and masses -- agrees with brute_force_seq_n_body on the same inputs to
  *    ~1e-13 relative; about 2.5x the default kernel's time;
  *  - MIXED MODE, nbx_ctx_set_refine(ctx, rel_tolerance, sigma_factor): fp32 for every target, then the targets whose fp32
  *    sum cannot be trusted to rel_tolerance are re-evaluated by the strict kernel.  The criterion (force_kernel.hip,
  *    refine_select_kernel): the rounding error of a target's fp32 sum has standard deviation ~ c u sqrt(Q_i), u = 2^-24,
- *    Q_i = sum over the 256-source tiles of |tile partial sum|^2 (accumulated by the fast kernel at no measurable cost);
- *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the tiles'
+ *    Q_i = sum over the 64-source blocks of |block partial sum|^2 (accumulated by the default three-level kernel at no measurable
+ *    cost; the two-level variant "fastpk_t8_w3_u4" sums over its 256-source tiles);
+ *    target i is re-evaluated when  rel_tolerance |a_i| < sigma_factor u sqrt(Q_i)  -- a chance cancellation: the blocks'
  *    pulls add up to far less than they are -- or when it is a close-set target.  sigma_factor = 0 takes the library's
  *    calibrated default (nbx_refine_sigma_default).  rel_tolerance = 0 switches the mode off; a new context starts with the
  *    process default (nbx_set_default_refine: 1e-5 unless changed).  Ignored with a softening length, the
@@ -334,7 +336,7 @@ int nbx_ctx_set_refine(nbx_ctx* ctx, double rel_tolerance, double sigma_factor);
  * (the same number: there is no capacity to overflow).  Either pointer may be NULL.  Synchronises the stream. */
 int nbx_ctx_refine_stats(nbx_ctx* ctx, unsigned* selected, unsigned* refined);
 /* The per-target statistic the last force evaluation wrote beside the accelerations, double[shard_len]:
- *   mixed mode:                  Q_i = sum over the source tiles of |tile partial sum|^2 (what the selection rule thresholds);
+ *   mixed mode:                  Q_i = sum over the source blocks of |block partial sum|^2 (what the selection rule thresholds);
  *   variant "strict_f64_t4_mag": S_i = sum_j |a_ij|, the sum of the pair terms' magnitudes (the yardstick of a cancelling
  *                                sum's error: backward error = |da_i| / S_i, condition number kappa_i = S_i / |a_i|).
  * NBX_ERR_STATE after any other evaluation.  Synchronises the stream. */
