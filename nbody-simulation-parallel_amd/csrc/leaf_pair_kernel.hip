@@ -47,9 +47,6 @@
 using namespace nbx;
 using namespace nbx_leaf;
 
-#ifndef NBX_LEAF_PERSIST
-#define NBX_LEAF_PERSIST 1   /* 0: A/B build without the persistent one-wave kernel */
-#endif
 #ifndef NBX_LEAF_PACK
 #define NBX_LEAF_PACK 1   /* 0: A/B build without packed small leaves (make LEAF_DEFS=-DNBX_LEAF_PACK=0 ...) */
 #endif
@@ -351,138 +348,6 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
     }
 }
 
-// PERSISTENT form of the one-wave-per-leaf kernel (small-leaf structures: plan.waves == 1, every leaf's list at most kMaxOps
-// runs).  A leaf of 8-16 bodies is a few microseconds of pair arithmetic behind a chain of three dependent memory round trips
-// (workgroup table -> copy runs -> first tile); with one workgroup per leaf that chain is paid per leaf, and at 5 waves per SIMD
-// half of a launch is waiting (profiles/r4).  Here a wave walks the leaves b, b + gridDim.x, ... and keeps the NEXT leaf's chain in
-// flight behind the current leaf's pair loop: the table entry two leaves ahead is requested at the top, the next leaf's targets
-// and copy runs are loaded while the current leaf's tiles run, and its first tile is requested right before the current leaf's
-// last tile is consumed.  Same arithmetic in the same order as leaf_pair_kernel<D, LAW, 1>: identical sums.
-template <int D, int LAW>
-__global__ __launch_bounds__(64) void leaf_pair_persist_kernel(LeafArgs a, uint32_t n_blocks) {
-    constexpr int kTileUnits = 64 * kUnitsPerLane;
-    __shared__ float4 tile[kTileUnits + 2 * kPadPairs + 16];
-    __shared__ uint32_t op_end[2][kMaxOps], op_base[2][kMaxOps];   // the current leaf's runs and the next leaf's
-    __shared__ double osum[3][64];
-    const unsigned lane = threadIdx.x;
-    const uint32_t stride = gridDim.x;
-    uint32_t b = blockIdx.x;
-    if (b >= n_blocks) return;
-    const bool mass_ok = *a.max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
-    const bool odd_unit = (lane & 1u) != 0u;
-    const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
-    const float4 pad_unit = make_float4(pad_xy, pad_xy, pad_zm, pad_zm);
-
-    struct Hdr { uint32_t op_lo, op_n, first, count; };
-    auto header = [&](uint32_t blk) -> Hdr {   // wave-uniform address: scalar loads
-        const LeafBlock* __restrict__ bp = a.blocks + blk;
-        return Hdr{bp->op_lo, bp->op_n, bp->piece[0].first, bp->piece[0].count};
-    };
-    // what a lane needs to know about a leaf: its target, its place among the lanes of that target, the leaf's stream
-    struct Leaf {
-        uint32_t pslot, u_end;
-        unsigned W, P, inv_P, g, t;
-        uint32_t valid;   // (a bool here leaves padding bytes that the compiler copies through scratch)
-        float ix, iy, iz;
-        CopyOp op;        // this lane's entry of the leaf's run table (lane < op_n), on its way to LDS
-        uint32_t op_n;
-    };
-    auto prepare = [&](const Hdr h) -> Leaf {   // issues the leaf's loads (targets, runs, stream length); nothing waits here
-        Leaf L;
-        L.W = h.count ? h.count : 1u;
-        const unsigned fit = 64u / L.W;
-        L.P = fit < (unsigned)kMaxLanesPerTarget ? fit : (unsigned)kMaxLanesPerTarget;
-        L.inv_P = (65536u + L.P - 1u) / L.P;
-        const unsigned g_raw = (unsigned)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)L.W));
-        L.t = lane - g_raw * L.W;
-        L.valid = (h.count != 0u && g_raw < L.P) ? 1u : 0u;
-        L.g = L.valid ? g_raw : 0u;
-        L.pslot = h.first + (L.valid ? L.t : 0u);
-        const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(L.pslot >> 1) * 8u + (L.pslot & 1u);
-        L.ix = xf[0]; L.iy = xf[2]; L.iz = (D == 3) ? xf[4] : 0.f;
-        L.op_n = h.op_n;
-        L.op = CopyOp{0u, 0u};
-        if (lane < h.op_n) L.op = a.ops[h.op_lo + lane];
-        L.u_end = h.op_n ? a.ops[h.op_lo + h.op_n - 1u].end : 0u;
-        return L;
-    };
-    unsigned k = 0;                                       // this lane's cursor in the runs of the leaf being staged
-    float4 nxt0 = pad_unit, nxt1 = pad_unit, nxt2 = pad_unit, nxt3 = pad_unit;
-    auto load_tile = [&](const unsigned tb, const uint32_t u_end, const uint32_t u0) {
-        auto load1 = [&](const uint32_t u, float4& v) {
-            v = pad_unit;
-            if (u < u_end) {
-                while (u >= op_end[tb][k]) ++k;
-                v = a.xp[op_base[tb][k] + u];
-            }
-        };
-        load1(u0 + lane, nxt0);
-        load1(u0 + 64u + lane, nxt1);
-        load1(u0 + 128u + lane, nxt2);
-        load1(u0 + 192u + lane, nxt3);
-    };
-    auto arm = [&](const Leaf& L, const unsigned tb) {    // the leaf's runs into table tb, its first tile into the staging registers
-        if (lane < L.op_n) { op_end[tb][lane] = L.op.end; op_base[tb][lane] = L.op.base; }
-        __syncthreads();
-        k = 0;
-        load_tile(tb, L.u_end, 0u);
-    };
-
-    Hdr h_next = (b + stride < n_blocks) ? header(b + stride) : Hdr{0u, 0u, 0u, 0u};
-    Leaf cur = prepare(header(b));
-    unsigned tb = 0;
-    arm(cur, tb);
-    for (;;) {
-        const uint32_t bn = b + stride;
-        const bool have_next = bn < n_blocks;
-        Leaf nx = cur;
-        if (have_next) {
-            nx = prepare(h_next);                                   // loads in flight behind this leaf's pair loop
-            if (bn + stride < n_blocks) h_next = header(bn + stride);
-        }
-        const f2 ix2 = {cur.ix, cur.ix}, iy2 = {cur.iy, cur.iy}, iz2 = {cur.iz, cur.iz};
-        const bool in_close_set = !(__builtin_fabsf(cur.ix) >= kCloseCoord && __builtin_fabsf(cur.iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(cur.iz) >= kCloseCoord));
-        const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && mass_ok;
-        Sums<D> S;
-        osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
-        S.o = &osum[0][lane];
-        S.stride = 64u;
-        bool armed = false;
-        for (uint32_t u0 = 0; u0 < cur.u_end; u0 += (uint32_t)kTileUnits) {
-            const unsigned n_units = (cur.u_end - u0 < (uint32_t)kTileUnits) ? (unsigned)(cur.u_end - u0) : (unsigned)kTileUnits;   // even
-            __syncthreads();                                        // the previous tile (or leaf) is done with the tile buffer
-            if (lane < n_units) tile[lane] = nxt0;
-            if (64u + lane < n_units) tile[64u + lane] = nxt1;
-            if (128u + lane < n_units) tile[128u + lane] = nxt2;
-            if (192u + lane < n_units) tile[192u + lane] = nxt3;
-            if (lane < 2u * (unsigned)kPadPairs) tile[n_units + lane] = pad_unit;
-            __syncthreads();
-            if (u0 + (uint32_t)kTileUnits < cur.u_end) load_tile(tb, cur.u_end, u0 + (uint32_t)kTileUnits);
-            else if (have_next) { arm(nx, tb ^ 1u); armed = true; }   // last tile: the next leaf's first tile rides behind it
-            const unsigned pairs = n_units >> 1;
-            const unsigned T = (((pairs + cur.P - 1u) * cur.inv_P) >> 16) | 1u;
-            const float4* s = tile + 2u * cur.g * T;
-            if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
-            else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
-        }
-        S.flush();
-        __syncthreads();
-        if (cur.valid && cur.g == 0u) {
-            double ox = 0.0, oy = 0.0, oz = 0.0;
-            for (unsigned q = 0; q < cur.P; ++q) { ox += osum[0][cur.t + q * cur.W]; oy += osum[1][cur.t + q * cur.W]; oz += osum[2][cur.t + q * cur.W]; }
-            a.acc[cur.pslot] = ox;
-            a.acc[(size_t)a.pslots + cur.pslot] = oy;
-            if (D == 3) a.acc[2 * (size_t)a.pslots + cur.pslot] = oz;
-        }
-        if (!have_next) break;
-        __syncthreads();                                            // the sums in LDS have been read before the next leaf zeroes them
-        if (!armed) arm(nx, tb ^ 1u);                               // (a leaf with an empty stream never got to it)
-        b = bn;
-        cur = nx;
-        tb ^= 1u;
-    }
-}
-
 // Packed small leaves (leaf_plan.h PackBlock): one wave64 = K = 64 / w leaves side by side.  The w lanes of a leaf do for it what
 // the two waves above do for theirs -- stage its stream (its own copy runs, its own cursor) into its own region of the tile,
 // then run the pair loop over it with P lanes per target -- and because w, P and the tile size are the block's, every lane of the
@@ -671,32 +536,6 @@ LeafKernel pick(int dim, int law, int waves) {
         {{leaf_pair_kernel<2, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<2, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<2, NBX_LAW_FMM_P2P, 2>},
          {leaf_pair_kernel<3, NBX_LAW_BRUTE, 2>, leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 2>, leaf_pair_kernel<3, NBX_LAW_FMM_P2P, 2>}}};
     return table[waves - 1][dim - 2][law];
-}
-
-typedef void (*PersistKernel)(LeafArgs, uint32_t);
-PersistKernel pick_persist(int dim, int law) {
-    static const PersistKernel table[2][3] = {
-        {leaf_pair_persist_kernel<2, NBX_LAW_BRUTE>, leaf_pair_persist_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pair_persist_kernel<2, NBX_LAW_FMM_P2P>},
-        {leaf_pair_persist_kernel<3, NBX_LAW_BRUTE>, leaf_pair_persist_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pair_persist_kernel<3, NBX_LAW_FMM_P2P>}};
-    return table[dim - 2][law];
-}
-// one-leaf workgroups: persistent waves when every workgroup is one wave and every list fits one run table
-hipError_t launch_leaf_blocks(int dim, int law, int waves, bool persist, const LeafArgs& a, size_t n_blocks, int num_cus, hipStream_t s) {
-    if (n_blocks == 0) return hipSuccess;
-    if (persist && waves == 1) {
-        // as many waves as the chip holds at once (the kernel's own occupancy: a wave that had to queue would start its share late)
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pick_persist(dim, law)), 64, 0) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            per_cu = 16;
-        }
-        size_t grid = (size_t)(num_cus > 0 ? num_cus : 256) * (size_t)per_cu;
-        if (grid > n_blocks) grid = n_blocks;
-        hipLaunchKernelGGL(pick_persist(dim, law), dim3((unsigned)grid), dim3(64), 0, s, a, (uint32_t)n_blocks);
-    } else {
-        hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)n_blocks), dim3(64u * (unsigned)waves), 0, s, a);
-    }
-    return hipGetLastError();
 }
 
 typedef void (*PackKernel)(LeafPackArgs);
@@ -932,10 +771,9 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     LeafArgs a;
     a.xp = xp; a.pslots = (uint32_t)pslots; a.ops = d_ops; a.blocks = d_blocks; a.acc = acc; a.max_mass_bits = d_max_mass;
     NBX_HIP_TRY(hipEventRecord(d.ev0, d.stream));
-    {   // one-leaf workgroups first: they are the long ones
-        int cus = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        NBX_HIP_TRY(launch_leaf_blocks(dim, law, waves, NBX_LEAF_PERSIST != 0 && plan.max_block_ops <= (uint32_t)kMaxOps, a, blocks.size(), cus, d.stream));
+    if (!blocks.empty()) {   // one-leaf workgroups first: they are the long ones
+        hipLaunchKernelGGL(pick(dim, law, waves), dim3((unsigned)blocks.size()), dim3(64u * (unsigned)waves), 0, d.stream, a);
+        NBX_HIP_TRY(hipGetLastError());
     }
     if (!plan.pack_blocks.empty()) {
         LeafPackArgs pa;
@@ -959,8 +797,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
 // (leaf_plan.h) and every device buffer an evaluation needs.  An evaluation is then: gather (16 B per slot from the resident
 // fp32 source copy), pair kernel, and -- only if the caller wants them on the host -- forces by body and one copy out.
 struct nbx_leaf_plan {
-    int device = 0, dim = 3, waves = 2, num_cus = 256;
-    bool persist = false;           // one-wave workgroups whose lists fit one run table: persistent waves (leaf_pair_persist_kernel)
+    int device = 0, dim = 3, waves = 2;
     size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0, n_subs = 0, n_packs = 0;
     char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass | packed leaves | packed waves
     float4* xp = nullptr;
@@ -1012,7 +849,8 @@ int plan_launch_pairs(nbx_leaf_plan* p, int law, hipStream_t s, bool timed) {
     if (p->n_blocks) {
         LeafArgs a;
         a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
-        NBX_HIP_TRY(launch_leaf_blocks(p->dim, law, p->waves, p->persist, a, p->n_blocks, p->num_cus, s));
+        hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
+        NBX_HIP_TRY(hipGetLastError());
     }
     if (p->n_packs) {
         LeafPackArgs pa;
@@ -1058,7 +896,6 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;
     p->pslots = host.pslots(); p->n_ops = host.ops.size(); p->n_blocks = host.blocks.size();
     p->n_subs = host.pack_subs.size(); p->n_packs = host.pack_blocks.size();
-    p->persist = NBX_LEAF_PERSIST != 0 && host.waves == 1 && host.max_block_ops <= (uint32_t)kMaxOps;
     std::vector<uint32_t> body_slot;
     try { body_slot.assign(n, 0xffffffffu); } catch (...) { delete p; return fail(NBX_ERR_ALLOC, "host allocation failed"); }
     for (size_t s = 0; s < p->pslots; ++s)
@@ -1070,7 +907,6 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
         if (e_ != hipSuccess) { const int r_ = nbx::fail_hip(e_, #expr, __FILE__, __LINE__); nbx_leaf_plan_destroy(p); return r_; } \
     } while (0)
     PLAN_TRY(hipSetDevice(device));
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cus = cus; }
     PLAN_TRY(nbx::take_stream(device, &p->stream));
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));

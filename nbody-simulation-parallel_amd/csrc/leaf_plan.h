@@ -89,7 +89,6 @@ struct LeafPlan {
     std::vector<uint32_t> op_off;       // [n_leaves + 1] leaf l's runs: ops[op_off[l] .. op_off[l+1])
     std::vector<LeafBlock> blocks;      // the one-leaf workgroups, longest first
     int waves = kMaxWaves;              // wave64 per one-leaf workgroup of this launch
-    uint32_t max_block_ops = 0;         // longest run list among the one-leaf workgroups (the persistent kernel holds one table of 64)
     std::vector<PackSub> pack_subs;     // packed small leaves ...
     std::vector<PackBlock> pack_blocks; // ... and the waves that take them, longest first
     size_t pslots() const { return unit_off.empty() ? 0 : unit_off.back(); }
@@ -160,7 +159,6 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     std::vector<LeafBlock>& blocks = plan.blocks;
     blocks.clear();
     blocks.reserve(n_leaves);
-    plan.max_block_ops = 0;
     {
         size_t nonempty_leaves = 0;
         for (size_t l = 0; l < n_leaves; ++l) nonempty_leaves += leaf_offsets[l + 1] > leaf_offsets[l];
@@ -213,7 +211,6 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             LeafBlock b;
             b.op_lo = op_off[l];
             b.op_n = op_off[l + 1] - op_off[l];
-            if (b.op_n > plan.max_block_ops) plan.max_block_ops = b.op_n;
             b.pad_[0] = b.pad_[1] = 0;
             b.piece[0] = Piece{f, c1};
             b.piece[1] = Piece{f + c1, share - c1};

@@ -1,7 +1,6 @@
 #!/usr/bin/env bash
 # A/B build of the library with the leaf-pair path compiled differently: nbody-simulation-parallel_amd/libnbody_hip_leafab.so.
 #   tools/build_ab_leaf.sh -DNBX_LEAF_PACK=0        without packed small leaves (csrc/leaf_plan.h PackBlock)
-#   tools/build_ab_leaf.sh -DNBX_LEAF_PERSIST=0     without the persistent one-wave kernel (leaf_pair_persist_kernel)
 # Select it for a Python tool with NBODY_HIP_LIBRARY=<path> (capi.py).  Measurement aid; not part of `make`.
 set -euo pipefail
 cd "$(dirname "$0")/.."
