@@ -905,9 +905,9 @@ template <int D>
 __global__ __launch_bounds__(256) void refine_fold_kernel(KArgs a) {
     const StrictLayout sl = strict_layout<D>(a);
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned items = sl.n * (unsigned)D;
-    for (unsigned item = blockIdx.x * 4u + (threadIdx.x >> 6); item < items; item += gridDim.x * 4u) {
-        const unsigned slot = item / (unsigned)D, k = item - slot * (unsigned)D;
+    const unsigned long long items = (unsigned long long)sl.n * (unsigned)D;   // (a shard may hold up to 2^31 targets)
+    for (unsigned long long item = blockIdx.x * 4u + (threadIdx.x >> 6); item < items; item += gridDim.x * 4u) {
+        const unsigned slot = (unsigned)(item / (unsigned)D), k = (unsigned)(item - (unsigned long long)slot * (unsigned)D);
         double v = 0.0;
         for (unsigned y = lane; y < sl.slices; y += 64u) v += a.strict_acc[((size_t)y * D + k) * sl.stride + slot];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
