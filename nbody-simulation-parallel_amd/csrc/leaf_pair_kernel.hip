@@ -47,6 +47,9 @@
 using namespace nbx;
 using namespace nbx_leaf;
 
+#ifndef NBX_LEAF_DIRECT
+#define NBX_LEAF_DIRECT 0   /* 1: A/B build in which the packed waves stream their sources straight from memory (leaf_direct_kernel) */
+#endif
 #ifndef NBX_LEAF_PACK
 #define NBX_LEAF_PACK 1   /* 0: A/B build without packed small leaves (make LEAF_DEFS=-DNBX_LEAF_PACK=0 ...) */
 #endif
@@ -447,6 +450,84 @@ __global__ __launch_bounds__(64) void leaf_pack_kernel(LeafPackArgs a) {
     }
 }
 
+// A/B (NBX_LEAF_DIRECT): the packed waves WITHOUT staging -- every lane streams its share of its leaf's source pairs straight from
+// memory (two 16-byte loads per pair; the lanes of a leaf's target share addresses, so a wave's load touches K x P distinct 32-byte
+// records), its leaf's runs in LDS, no tiles, no barriers in the loop, one iteration of loads in flight ahead of the arithmetic.
+template <int D, int LAW>
+__global__ __launch_bounds__(64) void leaf_direct_kernel(LeafPackArgs a) {
+    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps], op_base[kPackMaxSubs][kPackMaxOps];
+    __shared__ double osum[3][64];
+    const unsigned lane = threadIdx.x;
+    const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
+    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, longest = bp->longest;   // wave-uniform
+    const unsigned sub = lane >> wl, lw = lane & (w - 1u);
+    PackSub my = PackSub{0u, 0u, 0u, 0u};
+    if (sub < n_sub) my = a.subs[sub_lo + sub];
+    const uint32_t W = my.count ? my.count : 1u;
+    const unsigned g_raw = (unsigned)(((float)lw + 0.5f) * __builtin_amdgcn_rcpf((float)W));
+    const unsigned t = lw - g_raw * W;
+    const bool valid = my.count != 0u && g_raw < P;
+    const unsigned g = valid ? g_raw : 0u;
+    const uint32_t pslot = my.first + (valid ? t : 0u);
+    const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot >> 1) * 8u + (pslot & 1u);
+    float ix = 0.f, iy = 0.f, iz = 0.f;
+    if (my.count) { ix = xf[0]; iy = xf[2]; if (D == 3) iz = xf[4]; }
+    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+    const bool in_close_set = my.count != 0u && !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
+    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && *a.max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
+    for (unsigned k = lw; k < my.op_n; k += w) {
+        const CopyOp o = a.ops[my.op_lo + k];
+        op_end[sub][k] = o.end;
+        op_base[sub][k] = o.base;
+    }
+    const uint32_t u_end = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end : 0u;
+    // the wave's common trip count and this lane's share: lane group g of a target takes pairs [g T, (g + 1) T) of its leaf's stream
+    const unsigned T = ((longest >> 1) + P - 1u) / P;              // per lane group, for the longest stream of the wave (wave-uniform: scalar)
+    const uint32_t p_begin = g * T;
+    const uint32_t my_pairs = u_end >> 1;
+    const uint32_t p_stop = !valid ? 0u : (p_begin + T < my_pairs ? p_begin + T : my_pairs);   // lanes left over, and streams that end early, run on pads
+    const float4 padA = make_float4(kFar, kFar, kFar, kFar), padB = make_float4((D == 3) ? kFar : 0.0f, (D == 3) ? kFar : 0.0f, 0.0f, 0.0f);
+    Sums<D> S;
+    osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
+    S.o = &osum[0][lane];
+    S.stride = 64u;
+    __syncthreads();                                               // the run tables
+    unsigned k = 0;
+    const f2 bias = safe ? f2{kTiny, kTiny} : f2{0.f, 0.f};
+    auto fetch = [&](const uint32_t p, float4& A, float4& B) {
+        A = padA; B = padB;
+        if (p < p_stop) {
+            const uint32_t u = 2u * p;
+            while (u >= op_end[sub][k]) ++k;
+            const float4* __restrict__ src = a.xp + (op_base[sub][k] + u);
+            A = src[0]; B = src[1];
+        }
+    };
+    float4 A, B, An, Bn;
+    fetch(p_begin, A, B);
+    for (unsigned i = 0; i < T; ++i) {
+        fetch(p_begin + i + 1u, An, Bn);                           // in flight while this pair is computed (the last one fetches pads)
+        if (S.pending + 2u > kFlushTerms) S.flush();
+        const PairTerm<D> q(A, B, ix2, iy2, iz2, bias);
+        f2 wgt;
+        if (!safe && __builtin_expect(q.template special<LAW>() != 0ull, 0)) wgt = q.template guarded<LAW>();
+        else wgt = q.plain();
+        S.add(q, wgt);
+        S.pending += 2u;
+        A = An; B = Bn;
+    }
+    S.flush();
+    __syncthreads();
+    if (valid && g == 0u) {
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+        const unsigned l0 = sub * w + t;
+        for (unsigned q = 0; q < P; ++q) { ox += osum[0][l0 + q * W]; oy += osum[1][l0 + q * W]; oz += osum[2][l0 + q * W]; }
+        a.acc[pslot] = ox;
+        a.acc[(size_t)a.pslots + pslot] = oy;
+        if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
+    }
+}
+
 // staged Body<D> AoS fp64 (host order) -> leaf-ordered source pairs, fp32; a padded slot without a body is massless and far away
 __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restrict__ raw, size_t stride_d, int dim,
                                                           const uint32_t* __restrict__ pslot_body, uint32_t pslots, float* __restrict__ xp,
@@ -540,6 +621,12 @@ LeafKernel pick(int dim, int law, int waves) {
 
 typedef void (*PackKernel)(LeafPackArgs);
 PackKernel pick_pack(int dim, int law) {
+#if NBX_LEAF_DIRECT
+    static const PackKernel direct[2][3] = {
+        {leaf_direct_kernel<2, NBX_LAW_BRUTE>, leaf_direct_kernel<2, NBX_LAW_TREE_LEAF>, leaf_direct_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_direct_kernel<3, NBX_LAW_BRUTE>, leaf_direct_kernel<3, NBX_LAW_TREE_LEAF>, leaf_direct_kernel<3, NBX_LAW_FMM_P2P>}};
+    return direct[dim - 2][law];
+#endif
     static const PackKernel table[2][3] = {
         {leaf_pack_kernel<2, NBX_LAW_BRUTE>, leaf_pack_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<2, NBX_LAW_FMM_P2P>},
         {leaf_pack_kernel<3, NBX_LAW_BRUTE>, leaf_pack_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<3, NBX_LAW_FMM_P2P>}};

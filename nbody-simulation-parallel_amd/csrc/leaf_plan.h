@@ -30,12 +30,18 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // with leaves of their size class -- so that every lane runs the same trip count) -- and all of them run the pair loop together.  Everything else (larger leaves,
 // longer lists) keeps the one-leaf workgroups above.
 constexpr int kPackMaxTargets = 16;
-constexpr int kPackMaxOps = 16;
+#ifndef NBX_PACK_MAX_OPS
+#define NBX_PACK_MAX_OPS 16
+#endif
+constexpr int kPackMaxOps = NBX_PACK_MAX_OPS;
 // Packing is used for structures whose leaves hold at most this many bodies ON AVERAGE.  Measured at N = 2^20
 // (profiles/r4/leaf_pack_ab.txt, same box, back-to-back launches): 4-body grid leaves 0.226 -> 0.213 ms packed; median-split
 // leaves of 8 bodies 0.146 -> 0.203 ms and of 16 bodies 0.200 -> 0.273 ms (a leaf of 8-16 bodies fills a wave of its own at
 // 4-8 lanes per target; side by side on 8-16 lanes each they run one lane per target and a quarter of the waves).
-constexpr int kPackMeanLeaf = 6;
+#ifndef NBX_PACK_MEAN_LEAF
+#define NBX_PACK_MEAN_LEAF 6   /* A/B builds raise it to pack larger leaves too */
+#endif
+constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
 constexpr int kPackUnitsPerLane = 8;           // a sub-leaf's tile is 8 w units: 64 (w = 8) or 128 (w = 16) bodies
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -46,7 +52,8 @@ struct PackBlock {                             // one wave64; read with scalar l
     uint32_t w, P;                             // lanes per leaf (8 | 16), lanes per target (1 .. 8)
     uint32_t tiles;                            // tile iterations: ceil(longest stream / (kPackUnitsPerLane * w))
     uint32_t w_log2;                           // 3 | 4
-    uint32_t pad_[2];
+    uint32_t longest;                          // longest stream among the wave's leaves, in 16-byte units
+    uint32_t pad_;
 };
 static_assert(sizeof(PackSub) == 16 && sizeof(PackBlock) == 32, "read with vector / scalar loads");
 
@@ -196,6 +203,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             }
             const uint32_t tile_units = (uint32_t)kPackUnitsPerLane * w;
             b.tiles = (longest + tile_units - 1u) / tile_units;
+            b.longest = longest;
             packs.push_back(b);
         }
     }
