@@ -42,14 +42,12 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 using namespace nbx;
 using namespace nbx_leaf;
 
-#ifndef NBX_LEAF_DIRECT
-#define NBX_LEAF_DIRECT 0   /* 1: A/B build in which the packed waves stream their sources straight from memory (leaf_direct_kernel) */
-#endif
 #ifndef NBX_LEAF_PACK
 #define NBX_LEAF_PACK 1   /* 0: A/B build without packed small leaves (make LEAF_DEFS=-DNBX_LEAF_PACK=0 ...) */
 #endif
@@ -351,14 +349,20 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
     }
 }
 
-// Packed small leaves (leaf_plan.h PackBlock): one wave64 = K = 64 / w leaves side by side.  The w lanes of a leaf do for it what
-// the two waves above do for theirs -- stage its stream (its own copy runs, its own cursor) into its own region of the tile,
-// then run the pair loop over it with P lanes per target -- and because w, P and the tile size are the block's, every lane of the
-// wave runs the same trip counts: a leaf whose stream has ended, or that has fewer targets than lanes, computes on pad bodies
-// (massless, far away: exact zeros).  No workgroup barrier to speak of (one wave), one start-up per K leaves, every lane
-// group's LDS reads as conflict-free as above.
+// Packed small leaves (leaf_plan.h PackBlock): one wave64 = K = 64 / w leaves side by side, P lanes per target.  Nothing is staged:
+// lane group g of a target walks pairs [g T, (g + 1) T) of its leaf's source stream straight from memory (two 16-byte loads per
+// pair; the lanes of a leaf's targets share addresses, so a wave's load touches K x P distinct 32-byte records -- L2 hits, the
+// neighbouring leaves' lists name the same bodies).  The leaf's copy runs sit in LDS, the run a lane is in in registers.  Every
+// lane holds TWO targets (t and t + W of its leaf, W = ceil(count / 2) lanes per group): a loaded pair feeds four terms, which
+// halves the loads (the texture-address path limits a loop of 13 packed VALU per 32 bytes loaded by every lane) and the
+// bookkeeping per term.  The loop computes two pairs while the next two are in flight, two register sets taking turns (no
+// copies): four loads outstanding per lane, so that a wave waits for memory once per ~90 instructions rather than once per pair.  T is the block's (every lane of the
+// wave runs the same trips); a lane past its leaf's stream, or without a target, reads the launch's pad pair (massless, far
+// away: exact zeros) at unit `pslots`.  No barrier in the loop, one start-up per K leaves.
+// Replaces this round's first packed kernel (same blocks, each leaf's stream staged through its own region of an LDS tile):
+// 0.213 -> 0.140 ms at 4-body leaves, profiles/r4/leaf_direct_ab.txt.
 struct LeafPackArgs {
-    const float4* __restrict__ xp;
+    const float4* __restrict__ xp;     // [pslots + 2] units: the launch's pad pair behind the last leaf's
     uint32_t pslots;
     const CopyOp* __restrict__ ops;
     const PackBlock* __restrict__ blocks;
@@ -366,166 +370,131 @@ struct LeafPackArgs {
     double* __restrict__ acc;
     const uint32_t* __restrict__ max_mass_bits;
 };
-constexpr int kPackPadUnits = 2 * kPadPairs;     // pad units behind a region's tile: the lane groups' last trips reach up to 2 P - 1 pairs past it
-constexpr int kPackTileUnits = 64 * kPackUnitsPerLane;   // K regions x 8 w units = 512 units, whatever w
 constexpr int kPackMaxSubs = 8;                  // w >= 8
 
+#ifndef NBX_PACK_WAVES
+#define NBX_PACK_WAVES 4   /* waves per SIMD the register allocation aims at: 3D 110 VGPRs (5 spills 14 registers, 6 spills 34) */
+#endif
 template <int D, int LAW>
-__global__ __launch_bounds__(64) void leaf_pack_kernel(LeafPackArgs a) {
-    __shared__ float4 tile[kPackTileUnits + kPackMaxSubs * kPackPadUnits + 16];   // + what the pipelined pair loop reads ahead of its last trip
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAVES, 8))) void leaf_pack_kernel(LeafPackArgs a) {
     __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps], op_base[kPackMaxSubs][kPackMaxOps];
-    __shared__ double osum[3][64];
+    __shared__ double osum[3][128];                                // [component][second target? 64 : 0][lane]
     const unsigned lane = threadIdx.x;
     const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
-    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, tiles = bp->tiles, sub_lo = bp->sub_lo;   // wave-uniform
+    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, T = bp->trips;   // wave-uniform
     const unsigned sub = lane >> wl, lw = lane & (w - 1u);         // w = 1 << wl is 8 or 16
-    const unsigned R = (unsigned)kPackUnitsPerLane * w;            // units of one leaf's tile
     PackSub my = PackSub{0u, 0u, 0u, 0u};
     if (sub < n_sub) my = a.subs[sub_lo + sub];
-    const uint32_t W = my.count ? my.count : 1u;
+    // TWO targets per lane (t and t + W): a loaded source pair is used twice, and the loop's bookkeeping is shared by four terms
+    const uint32_t W = my.count ? (my.count + 1u) >> 1 : 1u;       // lanes per group
     // lw / W through fp32, as above ((lw + 0.5) / W is at least 1/32 away from an integer)
     const unsigned g_raw = (unsigned)(((float)lw + 0.5f) * __builtin_amdgcn_rcpf((float)W));
     const unsigned t = lw - g_raw * W;
     const bool valid = my.count != 0u && g_raw < P;
+    const bool valid1 = valid && t + W < my.count;                 // a leaf of odd size: its last lane holds one target
     const unsigned g = valid ? g_raw : 0u;
-    const uint32_t pslot = my.first + (valid ? t : 0u);
-    const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot >> 1) * 8u + (pslot & 1u);
-    float ix = 0.f, iy = 0.f, iz = 0.f;
-    if (my.count) { ix = xf[0]; iy = xf[2]; if (D == 3) iz = xf[4]; }
-    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-    const uint32_t max_mass_bits = *a.max_mass_bits;
+    const uint32_t pslot0 = my.first + (valid ? t : 0u), pslot1 = valid1 ? pslot0 + W : pslot0;
+    const float* __restrict__ xf0 = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot0 >> 1) * 8u + (pslot0 & 1u);
+    const float* __restrict__ xf1 = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot1 >> 1) * 8u + (pslot1 & 1u);
+    float ix = 0.f, iy = 0.f, iz = 0.f, jx = 0.f, jy = 0.f, jz = 0.f;
+    if (my.count) { ix = xf0[0]; iy = xf0[2]; jx = xf1[0]; jy = xf1[2]; if (D == 3) { iz = xf0[4]; jz = xf1[4]; } }
+    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz}, jx2 = {jx, jx}, jy2 = {jy, jy}, jz2 = {jz, jz};
     // lanes of an unused leaf slot hold no target: they must not drag the wave into the guarded loop
-    const bool in_close_set = my.count != 0u && !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
-    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
+    auto close = [](const float x, const float y, const float z) { return !(__builtin_fabsf(x) >= kCloseCoord && __builtin_fabsf(y) >= kCloseCoord && (D == 2 || __builtin_fabsf(z) >= kCloseCoord)); };
+    const bool in_close_set = my.count != 0u && (close(ix, iy, iz) || close(jx, jy, jz));
+    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && *a.max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
     // this leaf's copy runs and the length of its stream
     for (unsigned k = lw; k < my.op_n; k += w) {
         const CopyOp o = a.ops[my.op_lo + k];
         op_end[sub][k] = o.end;
         op_base[sub][k] = o.base;
     }
-    const uint32_t u_end = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end : 0u;
-    float4* __restrict__ region = tile + sub * (R + (unsigned)kPackPadUnits);
-    const bool odd_unit = (lw & 1u) != 0u;
-    const float pad_xy = odd_unit ? ((D == 3) ? kFar : 0.0f) : kFar, pad_zm = odd_unit ? 0.0f : kFar;
-    const float4 pad_unit = make_float4(pad_xy, pad_xy, pad_zm, pad_zm);
-    for (unsigned k = lw; k < (unsigned)kPackPadUnits + (sub + 1u == (64u >> wl) ? 16u : 0u); k += w) region[R + k] = pad_unit;   // written once: staging never touches them
-    Sums<D> S;
-    osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
-    S.o = &osum[0][lane];
-    S.stride = 64u;
-    const unsigned inv_P = (65536u + P - 1u) / P;
-    const unsigned pairs = R >> 1;
-    const unsigned T = (((pairs + P - 1u) * inv_P) >> 16) | 1u;     // the same for every lane of the wave
+    const uint32_t my_pairs = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end >> 1 : 0u;
+    const uint32_t p_begin = g * T;
+    const uint32_t p_stop = !valid ? 0u : (p_begin + T < my_pairs ? p_begin + T : my_pairs);
+    const uint32_t pad_unit = a.pslots;
+    Sums<D> S0, S1;
+    for (int c = 0; c < 3; ++c) { osum[c][lane] = 0.0; osum[c][64u + lane] = 0.0; }
+    S0.o = &osum[0][lane];
+    S1.o = &osum[0][64u + lane];
+    S0.stride = S1.stride = 128u;
     __syncthreads();                                               // the run tables (one wave: cheap)
     unsigned k = 0;                                                // this lane's cursor in its leaf's runs; only ever moves forward
-    for (uint32_t it = 0; it < tiles; ++it) {
-        const uint32_t u0 = it * R;
-        float4 v[kPackUnitsPerLane];
-#pragma unroll
-        for (int j = 0; j < kPackUnitsPerLane; ++j) {
-            const uint32_t u = u0 + lw + (uint32_t)j * w;
-            v[j] = pad_unit;
-            if (u < u_end) {
-                while (u >= op_end[sub][k]) ++k;
-                v[j] = a.xp[op_base[sub][k] + u];
-            }
+    uint32_t run_end = 0u, run_base = 0u;                          // the run it is in
+    auto unit_of = [&](const uint32_t p) -> uint32_t {             // where pair p of this lane's share lies
+        uint32_t u = pad_unit;
+        if (p < p_stop) {
+            const uint32_t v = 2u * p;
+            while (v >= run_end) { run_end = op_end[sub][k]; run_base = op_base[sub][k]; ++k; }
+            u = run_base + v;                                      // a run is whole leaves, a leaf whole pairs: both units of the pair
         }
-        __syncthreads();                                           // the previous tile has been consumed
+        return u;
+    };
+    auto issue = [&](const uint32_t p, float4 (&A)[2], float4 (&B)[2]) {
+        const uint32_t u0 = unit_of(p), u1 = unit_of(p + 1u);
+        A[0] = a.xp[u0]; B[0] = a.xp[u0 + 1u];
+        A[1] = a.xp[u1]; B[1] = a.xp[u1 + 1u];
+    };
+    static_assert(kPackPairsPerTrip == 2, "the loop below");
+    // the loop, once per form of the pair term (GUARD: a special case of the law is possible for one of this wave's targets)
+    auto run = [&](auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+        const f2 bias = GUARD ? f2{0.f, 0.f} : f2{kTiny, kTiny};
+        auto term = [&](const float4 A, const float4 B, const f2 x2, const f2 y2, const f2 z2, Sums<D>& S) {
+            const PairTerm<D> q(A, B, x2, y2, z2, bias);
+            f2 wgt;
+            if (GUARD && __builtin_expect(q.template special<LAW>() != 0ull, 0)) wgt = q.template guarded<LAW>();
+            else wgt = q.plain();
+            S.add(q, wgt);
+        };
+        auto compute = [&](const float4 (&A)[2], const float4 (&B)[2]) {
+            if (S0.pending + 4u > kFlushTerms) { S0.flush(); S1.flush(); }
 #pragma unroll
-        for (int j = 0; j < kPackUnitsPerLane; ++j) region[lw + (unsigned)j * w] = v[j];
-        __syncthreads();
-        const float4* s = region + 2u * g * T;
-        if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
-        else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
+            for (int j = 0; j < 2; ++j) {
+                term(A[j], B[j], ix2, iy2, iz2, S0);
+                term(A[j], B[j], jx2, jy2, jz2, S1);
+            }
+            S0.pending += 4u;
+        };
+        float4 A0[2], B0[2], A1[2], B1[2];
+        issue(p_begin, A0, B0);
+        for (uint32_t i = 0;;) {                                   // the loads past the share's end (and the last trip's) fetch the pad pair
+            issue(p_begin + i + 2u, A1, B1);
+            compute(A0, B0);
+            i += 2u;
+            if (i >= T) break;
+            issue(p_begin + i + 2u, A0, B0);
+            compute(A1, B1);
+            i += 2u;
+            if (i >= T) break;
+        }
+    };
+    if (T) {                                                       // wave-uniform
+        if (safe) run(std::false_type{});
+        else run(std::true_type{});
     }
-    S.flush();
+    S0.flush();
+    S1.flush();
     __syncthreads();
     if (valid && g == 0u) {
-        double ox = 0.0, oy = 0.0, oz = 0.0;
         const unsigned l0 = sub * w + t;
-        for (unsigned q = 0; q < P; ++q) { ox += osum[0][l0 + q * W]; oy += osum[1][l0 + q * W]; oz += osum[2][l0 + q * W]; }
-        a.acc[pslot] = ox;
-        a.acc[(size_t)a.pslots + pslot] = oy;
-        if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
+        for (unsigned h = 0; h < (valid1 ? 2u : 1u); ++h) {
+            double ox = 0.0, oy = 0.0, oz = 0.0;
+            for (unsigned q = 0; q < P; ++q) { ox += osum[0][64u * h + l0 + q * W]; oy += osum[1][64u * h + l0 + q * W]; oz += osum[2][64u * h + l0 + q * W]; }
+            const uint32_t pslot = h ? pslot1 : pslot0;
+            a.acc[pslot] = ox;
+            a.acc[(size_t)a.pslots + pslot] = oy;
+            if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
+        }
     }
 }
 
-// A/B (NBX_LEAF_DIRECT): the packed waves WITHOUT staging -- every lane streams its share of its leaf's source pairs straight from
-// memory (two 16-byte loads per pair; the lanes of a leaf's target share addresses, so a wave's load touches K x P distinct 32-byte
-// records), its leaf's runs in LDS, no tiles, no barriers in the loop, one iteration of loads in flight ahead of the arithmetic.
-template <int D, int LAW>
-__global__ __launch_bounds__(64) void leaf_direct_kernel(LeafPackArgs a) {
-    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps], op_base[kPackMaxSubs][kPackMaxOps];
-    __shared__ double osum[3][64];
-    const unsigned lane = threadIdx.x;
-    const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
-    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, longest = bp->longest;   // wave-uniform
-    const unsigned sub = lane >> wl, lw = lane & (w - 1u);
-    PackSub my = PackSub{0u, 0u, 0u, 0u};
-    if (sub < n_sub) my = a.subs[sub_lo + sub];
-    const uint32_t W = my.count ? my.count : 1u;
-    const unsigned g_raw = (unsigned)(((float)lw + 0.5f) * __builtin_amdgcn_rcpf((float)W));
-    const unsigned t = lw - g_raw * W;
-    const bool valid = my.count != 0u && g_raw < P;
-    const unsigned g = valid ? g_raw : 0u;
-    const uint32_t pslot = my.first + (valid ? t : 0u);
-    const float* __restrict__ xf = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot >> 1) * 8u + (pslot & 1u);
-    float ix = 0.f, iy = 0.f, iz = 0.f;
-    if (my.count) { ix = xf[0]; iy = xf[2]; if (D == 3) iz = xf[4]; }
-    const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-    const bool in_close_set = my.count != 0u && !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
-    const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && *a.max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
-    for (unsigned k = lw; k < my.op_n; k += w) {
-        const CopyOp o = a.ops[my.op_lo + k];
-        op_end[sub][k] = o.end;
-        op_base[sub][k] = o.base;
-    }
-    const uint32_t u_end = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end : 0u;
-    // the wave's common trip count and this lane's share: lane group g of a target takes pairs [g T, (g + 1) T) of its leaf's stream
-    const unsigned T = ((longest >> 1) + P - 1u) / P;              // per lane group, for the longest stream of the wave (wave-uniform: scalar)
-    const uint32_t p_begin = g * T;
-    const uint32_t my_pairs = u_end >> 1;
-    const uint32_t p_stop = !valid ? 0u : (p_begin + T < my_pairs ? p_begin + T : my_pairs);   // lanes left over, and streams that end early, run on pads
-    const float4 padA = make_float4(kFar, kFar, kFar, kFar), padB = make_float4((D == 3) ? kFar : 0.0f, (D == 3) ? kFar : 0.0f, 0.0f, 0.0f);
-    Sums<D> S;
-    osum[0][lane] = 0.0; osum[1][lane] = 0.0; osum[2][lane] = 0.0;
-    S.o = &osum[0][lane];
-    S.stride = 64u;
-    __syncthreads();                                               // the run tables
-    unsigned k = 0;
-    const f2 bias = safe ? f2{kTiny, kTiny} : f2{0.f, 0.f};
-    auto fetch = [&](const uint32_t p, float4& A, float4& B) {
-        A = padA; B = padB;
-        if (p < p_stop) {
-            const uint32_t u = 2u * p;
-            while (u >= op_end[sub][k]) ++k;
-            const float4* __restrict__ src = a.xp + (op_base[sub][k] + u);
-            A = src[0]; B = src[1];
-        }
-    };
-    float4 A, B, An, Bn;
-    fetch(p_begin, A, B);
-    for (unsigned i = 0; i < T; ++i) {
-        fetch(p_begin + i + 1u, An, Bn);                           // in flight while this pair is computed (the last one fetches pads)
-        if (S.pending + 2u > kFlushTerms) S.flush();
-        const PairTerm<D> q(A, B, ix2, iy2, iz2, bias);
-        f2 wgt;
-        if (!safe && __builtin_expect(q.template special<LAW>() != 0ull, 0)) wgt = q.template guarded<LAW>();
-        else wgt = q.plain();
-        S.add(q, wgt);
-        S.pending += 2u;
-        A = An; B = Bn;
-    }
-    S.flush();
-    __syncthreads();
-    if (valid && g == 0u) {
-        double ox = 0.0, oy = 0.0, oz = 0.0;
-        const unsigned l0 = sub * w + t;
-        for (unsigned q = 0; q < P; ++q) { ox += osum[0][l0 + q * W]; oy += osum[1][l0 + q * W]; oz += osum[2][l0 + q * W]; }
-        a.acc[pslot] = ox;
-        a.acc[(size_t)a.pslots + pslot] = oy;
-        if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
-    }
+// the launch's pad pair, behind the last leaf's slots (pslots is even: every leaf is padded to whole pairs); the arrays' arena keeps
+// 256 bytes of slack behind each of them
+__device__ __forceinline__ void write_pad_pair(float* __restrict__ xp, uint32_t pslots, int dim) {
+    float* __restrict__ o = xp + (size_t)pslots * 4u;
+    const float zc = dim == 3 ? kFar : 0.0f;
+    o[0] = kFar; o[1] = kFar; o[2] = kFar; o[3] = kFar; o[4] = zc; o[5] = zc; o[6] = 0.0f; o[7] = 0.0f;
 }
 
 // staged Body<D> AoS fp64 (host order) -> leaf-ordered source pairs, fp32; a padded slot without a body is massless and far away
@@ -547,6 +516,7 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restri
     }
     // one lane per wave, and only while the wave's maximum is above what is already there (16,384 atomics on one word cost 0.15 ms)
     if ((threadIdx.x & 63u) == 0u && mb > __atomic_load_n(max_mass_bits, __ATOMIC_RELAXED)) atomicMax(max_mass_bits, mb);
+    if (p == 0u) write_pad_pair(xp, pslots, dim);
     if (p >= pslots) return;
     float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
     o[0] = x; o[2] = y; o[4] = z; o[6] = m;
@@ -592,6 +562,7 @@ __global__ __launch_bounds__(256) void leaf_gather_by_body_kernel(const float* _
 
 __global__ __launch_bounds__(256) void leaf_init_pads_kernel(const uint32_t* __restrict__ pslot_body, uint32_t pslots, int dim, float* __restrict__ xp) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p == 0u) write_pad_pair(xp, pslots, dim);
     if (p >= pslots || pslot_body[p] != 0xffffffffu) return;
     float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
     o[0] = kFar; o[2] = kFar; o[4] = dim == 3 ? kFar : 0.0f; o[6] = 0.0f;   // a leaf's pad: massless and far away
@@ -621,12 +592,6 @@ LeafKernel pick(int dim, int law, int waves) {
 
 typedef void (*PackKernel)(LeafPackArgs);
 PackKernel pick_pack(int dim, int law) {
-#if NBX_LEAF_DIRECT
-    static const PackKernel direct[2][3] = {
-        {leaf_direct_kernel<2, NBX_LAW_BRUTE>, leaf_direct_kernel<2, NBX_LAW_TREE_LEAF>, leaf_direct_kernel<2, NBX_LAW_FMM_P2P>},
-        {leaf_direct_kernel<3, NBX_LAW_BRUTE>, leaf_direct_kernel<3, NBX_LAW_TREE_LEAF>, leaf_direct_kernel<3, NBX_LAW_FMM_P2P>}};
-    return direct[dim - 2][law];
-#endif
     static const PackKernel table[2][3] = {
         {leaf_pack_kernel<2, NBX_LAW_BRUTE>, leaf_pack_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<2, NBX_LAW_FMM_P2P>},
         {leaf_pack_kernel<3, NBX_LAW_BRUTE>, leaf_pack_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<3, NBX_LAW_FMM_P2P>}};

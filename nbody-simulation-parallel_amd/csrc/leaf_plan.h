@@ -2,6 +2,8 @@
 // call from the caller's CSR arrays.  Plain C++ (no HIP): tests/test_leaf_plan_cpu.py compiles it with g++ and checks its
 // invariants without a GPU.  The comment at the top of leaf_pair_kernel.hip says what each piece is for.
 #pragma once
+#include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -26,31 +28,33 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // A leaf of a few bodies cannot fill a wave: at 4 bodies per leaf a workgroup's start-up, staging and closing reduction cost ten
 // times its pair arithmetic (0.06 of the fp32 peak in round 3).  Leaves of up to kPackMaxTargets bodies whose list is at most
 // kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 8 or 16 lanes --
-// its own copy runs, its own region of the LDS tile, P lanes per target (the same for every leaf of the wave -- leaves are packed
-// with leaves of their size class -- so that every lane runs the same trip count) -- and all of them run the pair loop together.  Everything else (larger leaves,
-// longer lists) keeps the one-leaf workgroups above.
+// its own copy runs, P lane groups (two targets per lane; the same P for every leaf of the wave -- leaves are packed with leaves of their size class
+// -- so that every lane runs the same trip count), each lane group streaming its share of its leaf's source pairs straight from
+// memory -- and all of them run the pair loop together.  Everything else (larger leaves, longer lists) keeps the one-leaf
+// workgroups above.
 constexpr int kPackMaxTargets = 16;
 #ifndef NBX_PACK_MAX_OPS
 #define NBX_PACK_MAX_OPS 16
 #endif
 constexpr int kPackMaxOps = NBX_PACK_MAX_OPS;
 // Packing is used for structures whose leaves hold at most this many bodies ON AVERAGE.  Measured at N = 2^20
-// (profiles/r4/leaf_pack_ab.txt, same box, back-to-back launches): 4-body grid leaves 0.226 -> 0.213 ms packed; median-split
-// leaves of 8 bodies 0.146 -> 0.203 ms and of 16 bodies 0.200 -> 0.273 ms (a leaf of 8-16 bodies fills a wave of its own at
-// 4-8 lanes per target; side by side on 8-16 lanes each they run one lane per target and a quarter of the waves).
+// (profiles/r4/leaf_pack_ab.txt, leaf_direct_ab.txt; same box, back-to-back launches): 4-body grid leaves 0.226 ms one workgroup
+// per leaf, 0.213 ms packed and staged through LDS (this round's first packed kernel), 0.140 ms packed and streamed; median-split
+// leaves of 8 bodies 0.146 -> 0.194 ms and of 16 bodies 0.209 -> 0.373 ms (a leaf of 8-16 bodies fills a wave of its own at
+// 4-8 lanes per target and shares its staged sources among them; side by side every lane loads its own).
 #ifndef NBX_PACK_MEAN_LEAF
 #define NBX_PACK_MEAN_LEAF 6   /* A/B builds raise it to pack larger leaves too */
 #endif
 constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
-constexpr int kPackUnitsPerLane = 8;           // a sub-leaf's tile is 8 w units: 64 (w = 8) or 128 (w = 16) bodies
+constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
     uint32_t first, count;                     // its targets (padded slots)
 };
 struct PackBlock {                             // one wave64; read with scalar loads
     uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
-    uint32_t w, P;                             // lanes per leaf (8 | 16), lanes per target (1 .. 8)
-    uint32_t tiles;                            // tile iterations: ceil(longest stream / (kPackUnitsPerLane * w))
+    uint32_t w, P;                             // lanes per leaf (8 | 16), lane groups per leaf (2 | 4 | 8): each walks 1 / P of the stream
+    uint32_t trips;                            // source pairs every lane group walks: ceil(longest stream's pairs / P), rounded up to kPackPairsPerTrip
     uint32_t w_log2;                           // 3 | 4
     uint32_t longest;                          // longest stream among the wave's leaves, in 16-byte units
     uint32_t pad_;
@@ -100,6 +104,52 @@ struct LeafPlan {
     std::vector<PackBlock> pack_blocks; // ... and the waves that take them, longest first
     size_t pslots() const { return unit_off.empty() ? 0 : unit_off.back(); }
 };
+
+// The order of a launch's workgroups.
+//  * Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
+//    short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).
+//    A counting sort over 1024 duration classes, leaf order kept within a class.
+//  * One eighth of the structure per XCD: workgroup i runs on XCD i % 8 and every XCD has an L2 of its own, so with a class in
+//    plain leaf order every one of the eight L2s ends up fetching every body of the launch.  From kXcdOrderFrom workgroups on,
+//    the blocks of a duration class (in leaf order) are cut into eight runs, and run x takes the indices of the class that are
+//    x mod 8: XCD x sees the x-th eighth of every class -- for a structure whose durations do not follow position, the same
+//    eighth of space throughout -- while every stretch of the index space still holds blocks of one duration (dispatch is in
+//    order: eight runs of unequal durations side by side were measured 40 % SLOWER at 4-body leaves, the XCDs with the short
+//    blocks waiting for the dispatcher to get past the ones with the long blocks).
+constexpr uint32_t kXcds = 8;
+#ifndef NBX_XCD_ORDER_FROM
+#define NBX_XCD_ORDER_FROM 4096
+#endif
+constexpr size_t kXcdOrderFrom = NBX_XCD_ORDER_FROM;
+template <class Block, class Dur>
+inline void order_launch(std::vector<Block>& v, Dur dur) {
+    const size_t n = v.size();
+    if (n < 2) return;
+    uint32_t longest = 1;
+    for (const Block& b : v) if (dur(b) > longest) longest = dur(b);
+    constexpr uint32_t kClasses = 1024;
+    auto cls = [&](const Block& b) -> uint32_t { return (kClasses - 1u) - (uint32_t)((uint64_t)dur(b) * (kClasses - 1u) / longest); };
+    std::vector<uint32_t> start(kClasses + 2, 0u);
+    for (const Block& b : v) ++start[cls(b) + 2u];
+    for (uint32_t k = 0; k <= kClasses; ++k) start[k + 1] += start[k];      // start[k + 1]: first index of class k
+    std::vector<Block> sorted(n);
+    for (const Block& b : v) sorted[start[cls(b) + 1u]++] = b;              // afterwards start[k + 1] = end of class k, start[k] = its begin
+    if (n < kXcdOrderFrom) { v.swap(sorted); return; }
+    for (uint32_t k = 0; k < kClasses; ++k) {
+        const size_t b0 = start[k], b1 = start[k + 1];
+        if (b1 - b0 < 2u * kXcds) { std::copy(sorted.begin() + (ptrdiff_t)b0, sorted.begin() + (ptrdiff_t)b1, v.begin() + (ptrdiff_t)b0); continue; }
+        size_t first[kXcds], run_lo[kXcds], at = b0;                       // first index of the class that is x mod 8; where run x starts
+        for (uint32_t x = 0; x < kXcds; ++x) {
+            first[x] = b0 + (x + kXcds - (uint32_t)(b0 % kXcds)) % kXcds;
+            run_lo[x] = at;
+            at += first[x] < b1 ? (b1 - first[x] + kXcds - 1u) / kXcds : 0u;
+        }
+        for (size_t i = b0; i < b1; ++i) {
+            const uint32_t x = (uint32_t)(i % kXcds);
+            v[i] = sorted[run_lo[x] + (i - first[x]) / kXcds];
+        }
+    }
+}
 
 // The CSR arrays must have been validated (offsets non-decreasing from 0, every index in range).  Returns nullptr, or why the
 // structure cannot be laid out (more than 2^32 units).
@@ -171,27 +221,36 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
         for (size_t l = 0; l < n_leaves; ++l) nonempty_leaves += leaf_offsets[l + 1] > leaf_offsets[l];
         pack_small_leaves = pack_small_leaves && nonempty_leaves && slots <= (size_t)kPackMeanLeaf * nonempty_leaves;
     }
-    // packed waves.  Leaves are packed with leaves of their own SIZE CLASS -- 1, 2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2, 1
-    // lanes per target), 9-16 bodies on 16 lanes -- in leaf order within the class, so that every wave runs the most lanes per
-    // target its leaves allow (mixed, one 8-body leaf would hold seven smaller ones at one lane per target).
+    // packed waves.  A lane holds two targets, so a leaf of c bodies takes ceil(c / 2) lanes per lane group.  Leaves are packed
+    // with leaves of their own SIZE CLASS -- 1-2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2 lane groups), 9-16 bodies on 16 lanes
+    // (2 groups) -- in leaf order within the class, so that every wave runs the most lane groups its leaves allow (mixed, one
+    // 8-body leaf would hold seven smaller ones at two groups).
     std::vector<PackSub>& subs = plan.pack_subs;
     std::vector<PackBlock>& packs = plan.pack_blocks;
     subs.clear();
     packs.clear();
-    auto size_class = [](uint32_t c) -> int { return c <= 1u ? 0 : c <= 2u ? 1 : c <= 4u ? 2 : c <= 8u ? 3 : 4; };
-    std::vector<uint32_t> packable[5];
+    auto size_class = [](uint32_t c) -> int { return c <= 2u ? 0 : c <= 4u ? 1 : c <= 8u ? 2 : 3; };
+    std::vector<uint32_t> packable[4];
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (pack_small_leaves && c >= 1u && c <= (uint32_t)kPackMaxTargets && op_off[l + 1] - op_off[l] <= (uint32_t)kPackMaxOps)
             packable[size_class(c)].push_back((uint32_t)l);
     }
-    for (int k = 0; k < 5; ++k) {
-        const uint32_t w = k == 4 ? 16u : 8u, per_wave = 64u / w;
-        const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : k == 2 ? 2u : 1u;
+    auto stream_of = [&](uint32_t l) -> uint32_t { const uint32_t n_ops = op_off[l + 1] - op_off[l]; return n_ops ? ops[op_off[l] + n_ops - 1].end : 0u; };
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = k == 3 ? 16u : 8u, per_wave = 64u / w;
+        const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : 2u;
+        // a wave runs as long as its longest leaf: within every window of eight waves' leaves (neighbours: the locality stays) the
+        // leaves are taken longest stream first, so that a wave's leaves are of nearly one length (a 27-cell neighbourhood of
+        // ~4.5-body cells: the longest of 8 random ones is 12 % above the mean, of 8 consecutive ones of a sorted 64 2 %)
+        for (size_t i = 0; i < packable[k].size(); i += 8u * per_wave) {
+            const size_t e = i + 8u * per_wave < packable[k].size() ? i + 8u * per_wave : packable[k].size();
+            std::stable_sort(packable[k].begin() + (ptrdiff_t)i, packable[k].begin() + (ptrdiff_t)e, [&](uint32_t x, uint32_t y) { return stream_of(x) > stream_of(y); });
+        }
         for (size_t i = 0; i < packable[k].size(); i += per_wave) {
             PackBlock b{};
             b.sub_lo = (uint32_t)subs.size();
-            b.w = w; b.w_log2 = k == 4 ? 4u : 3u; b.P = P;
+            b.w = w; b.w_log2 = k == 3 ? 4u : 3u; b.P = P;
             uint32_t longest = 0;
             for (size_t j = i; j < packable[k].size() && j < i + per_wave; ++j) {
                 const uint32_t l = packable[k][j];
@@ -201,8 +260,8 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
                 ++b.n_sub;
                 if (stream > longest) longest = stream;
             }
-            const uint32_t tile_units = (uint32_t)kPackUnitsPerLane * w;
-            b.tiles = (longest + tile_units - 1u) / tile_units;
+            const uint32_t per_group = ((longest >> 1) + P - 1u) / P;   // streams are whole pairs (every leaf is padded to an even size)
+            b.trips = (per_group + (uint32_t)kPackPairsPerTrip - 1u) / (uint32_t)kPackPairsPerTrip * (uint32_t)kPackPairsPerTrip;
             b.longest = longest;
             packs.push_back(b);
         }
@@ -232,31 +291,8 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             f += share;
         }
     }
-    if (packs.size() > 1) {   // longest first, stable (leaf order kept among waves of equal length)
-        std::vector<PackBlock> sorted(packs);
-        uint32_t longest = 0;
-        for (const PackBlock& b : packs) if (b.tiles > longest) longest = b.tiles;
-        std::vector<uint32_t> start(longest + 2, 0u);
-        for (const PackBlock& b : packs) ++start[longest - b.tiles + 1u];
-        for (uint32_t k = 0; k <= longest; ++k) start[k + 1] += start[k];
-        for (const PackBlock& b : packs) sorted[start[longest - b.tiles]++] = b;
-        packs.swap(sorted);
-    }
-    // Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
-    // short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).
-    // A counting sort over 1024 duration classes, leaf order kept within a class (neighbours share their sources in L2).
-    if (blocks.size() > 1) {
-        uint32_t longest = 1;
-        for (const LeafBlock& b : blocks) if (b.pad_[0] > longest) longest = b.pad_[0];
-        constexpr uint32_t kClasses = 1024;
-        auto cls = [&](const LeafBlock& b) -> uint32_t { return (kClasses - 1u) - (uint32_t)((uint64_t)b.pad_[0] * (kClasses - 1u) / longest); };
-        std::vector<uint32_t> start(kClasses + 1, 0u);
-        for (const LeafBlock& b : blocks) ++start[cls(b) + 1u];
-        for (uint32_t k = 0; k < kClasses; ++k) start[k + 1] += start[k];
-        std::vector<LeafBlock> sorted(blocks.size());
-        for (const LeafBlock& b : blocks) sorted[start[cls(b)]++] = b;
-        blocks.swap(sorted);
-    }
+    order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips; });
+    order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
 
     return nullptr;
 }

@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAD = 0xFFFFFFFF
 
 
-@pytest.fixture(scope="module")
-def planner(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("leaf_plan") / "leaf_plan_check")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], check=True)
+def _build_planner(tmp_path_factory, name, *defines):
+    exe = str(tmp_path_factory.mktemp(name) / "leaf_plan_check")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", *defines,
+                    os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], check=True)
 
     def run(workdir, lo, lb, so, ss):
         for name, a in (("leaf_offsets", lo), ("leaf_bodies", lb), ("list_offsets", so), ("list_sources", ss)):
@@ -25,12 +25,23 @@ def planner(tmp_path_factory):
         out = {k: np.fromfile(os.path.join(workdir, k + ".u32"), dtype=np.uint32)
                for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks", "pack_subs", "pack_blocks")}
         out["pack_subs"] = out["pack_subs"].reshape(-1, 4)      # op_lo, op_n, first, count
-        out["pack_blocks"] = out["pack_blocks"].reshape(-1, 8)  # sub_lo, n_sub, w, P, tiles, -, -, -
+        out["pack_blocks"] = out["pack_blocks"].reshape(-1, 8)  # sub_lo, n_sub, w, P, trips, w_log2, longest, -
         out["waves"] = int(p.stdout.split()[1])
         out["ops"] = out["ops"].reshape(-1, 2)          # (end, base)
         out["blocks"] = out["blocks"].reshape(-1, 8)    # op_lo, op_n, key, -, first0, count0, first1, count1
         return out
     return run
+
+
+@pytest.fixture(scope="module")
+def planner(tmp_path_factory):
+    return _build_planner(tmp_path_factory, "leaf_plan")
+
+
+@pytest.fixture(scope="module")
+def planner_xcd(tmp_path_factory):
+    """The same planner with the XCD-aware order switched on from 16 workgroups (the library: from 4,096), so that structures of test size reach it."""
+    return _build_planner(tmp_path_factory, "leaf_plan_xcd", "-DNBX_XCD_ORDER_FROM=16")
 
 
 def _structure(seed, sizes, list_len):
@@ -106,18 +117,21 @@ def _check(plan, lo, lb, so, ss):
     subs, packs = plan["pack_subs"].astype(np.int64), plan["pack_blocks"].astype(np.int64)
     n_ops_of = np.diff(op_off.astype(np.int64))
     seen_sub = np.zeros(subs.shape[0], dtype=np.int64)
-    for sub_lo, n_sub, w, P, tiles, *_ in packs:
+    for sub_lo, n_sub, w, P, trips, _, longest, _ in packs:
         assert w in (8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
         assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 16).all()
-        # leaves share a wave with leaves of their size class: 1, 2, 3-4, 5-8 bodies on 8 lanes (8, 4, 2, 1 lanes per target), 9-16 on 16
-        cls = lambda c: 0 if c <= 1 else 1 if c <= 2 else 2 if c <= 4 else 3 if c <= 8 else 4
+        # leaves share a wave with leaves of their size class (a lane holds two targets): 1-2, 3-4, 5-8 bodies on 8 lanes
+        # (8, 4, 2 lane groups), 9-16 bodies on 16 lanes (2 groups)
+        cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 8 else 3
         k = cls(mine[0, 3])
-        assert all(cls(c) == k for c in mine[:, 3]) and w == (16 if k == 4 else 8) and P == (8, 4, 2, 1, 1)[k]
-        assert (mine[:, 3] * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
+        assert all(cls(c) == k for c in mine[:, 3]) and w == (16 if k == 3 else 8) and P == (8, 4, 2, 2)[k]
+        assert (-(-mine[:, 3] // 2) * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
         streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
-        assert tiles == -(-max(streams) // int(8 * w))
+        # every lane group walks the same number of source pairs: its share of the longest stream, an even number (the loop takes two at a time)
+        assert longest == max(streams) and longest % 2 == 0
+        assert trips == -(-(-(-(longest // 2) // P)) // 2) * 2 and trips * P * 2 >= longest
         for o, k, f, c in mine:
             l = leaf_of_unit[f]
             assert sizes[l] == c and f == unit_off[l] and o == op_off[l] and k == n_ops_of[l]
@@ -172,3 +186,51 @@ def test_grid_neighbourhoods_become_a_few_runs(planner, tmp_path):
     runs = np.diff(plan["op_off"].astype(np.int64))
     assert runs.max() <= 11 and runs.min() >= 4 and np.diff(so).max() == 27, (runs.min(), runs.max())
     assert plan["waves"] == 2
+
+
+def _check_xcd_runs(keys, where):
+    """Within a duration class of >= 16 workgroups, the workgroups at indices x mod 8 are the x-th of eight consecutive runs of the
+    class in leaf order (`where`: a position that grows with the leaf), run lengths differing by at most one."""
+    cls = keys * 1023 // max(int(keys.max()), 1)
+    assert (np.diff(cls) <= 0).all()
+    checked = 0
+    edges = np.flatnonzero(np.diff(cls)) + 1
+    for b0, b1 in zip(np.r_[0, edges], np.r_[edges, cls.size]):
+        idx = np.arange(b0, b1)
+        if b1 - b0 < 16:
+            assert (np.diff(where[idx]) > 0).all()              # small classes stay in leaf order
+            continue
+        runs = [where[idx[idx % 8 == x]] for x in range(8)]
+        for x in range(8):
+            assert (np.diff(runs[x]) > 0).all()
+            if x:
+                assert runs[x - 1].max() < runs[x].min()
+        assert max(len(r) for r in runs) - min(len(r) for r in runs) <= 1
+        checked += 1
+    return checked
+
+
+def test_workgroups_of_a_class_are_dealt_to_the_xcds_in_runs(planner_xcd, tmp_path):
+    """csrc/leaf_plan.h order_launch: workgroup i runs on XCD i % 8; every XCD takes one contiguous eighth (in leaf order) of each
+    duration class.  Checked for the one-leaf workgroups (larger leaves) and the packed waves (tiny leaves), with every other
+    invariant of the plan."""
+    big = [40] * 700                                     # equal leaves: a list's length alone decides the duration -> a few large classes
+    d = tmp_path / "big"
+    d.mkdir()
+    lo, lb, so, ss = _structure(11, big, lambda t: [3, 9, 27, 5][t % 4])
+    plan = planner_xcd(str(d), lo, lb, so, ss)
+    _check(plan, lo, lb, so, ss)
+    blocks = plan["blocks"].astype(np.int64)
+    assert blocks.shape[0] >= 700 and plan["pack_blocks"].shape[0] == 0
+    assert _check_xcd_runs(blocks[:, 2], blocks[:, 4]) >= 3
+    tiny = [4] * 6000
+    d = tmp_path / "tiny"
+    d.mkdir()
+    lo, lb, so, ss = _structure(12, tiny, lambda t: [3, 9, 12][(t // 8) % 3])       # eight leaves to a wave: waves of three durations
+    plan = planner_xcd(str(d), lo, lb, so, ss)
+    _check(plan, lo, lb, so, ss)
+    packs, subs = plan["pack_blocks"].astype(np.int64), plan["pack_subs"].astype(np.int64)
+    assert packs.shape[0] >= 500
+    # packed waves of one duration class can belong to different size classes (built class by class, each in leaf order): the runs are
+    # consecutive in BUILD order, which is the order of their first sub-leaf
+    assert _check_xcd_runs(packs[:, 4], packs[:, 0]) >= 2
