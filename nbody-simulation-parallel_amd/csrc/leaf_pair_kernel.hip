@@ -430,10 +430,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         }
         return u;
     };
+    // 32-bit byte offsets from a scalar base (the plan packs nothing beyond 2^28 units): one shift per pair, the second unit at an immediate offset
+    const char* __restrict__ const xp_bytes = reinterpret_cast<const char*>(a.xp);
     auto issue = [&](const uint32_t p, float4 (&A)[2], float4 (&B)[2]) {
-        const uint32_t u0 = unit_of(p), u1 = unit_of(p + 1u);
-        A[0] = a.xp[u0]; B[0] = a.xp[u0 + 1u];
-        A[1] = a.xp[u1]; B[1] = a.xp[u1 + 1u];
+        const uint32_t o0 = unit_of(p) << 4, o1 = unit_of(p + 1u) << 4;
+        const float4* __restrict__ s0 = reinterpret_cast<const float4*>(xp_bytes + o0);
+        const float4* __restrict__ s1 = reinterpret_cast<const float4*>(xp_bytes + o1);
+        A[0] = s0[0]; B[0] = s0[1];
+        A[1] = s1[0]; B[1] = s1[1];
     };
     static_assert(kPackPairsPerTrip == 2, "the loop below");
     // the loop, once per form of the pair term (GUARD: a special case of the law is possible for one of this wave's targets)
@@ -458,16 +462,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         };
         float4 A0[2], B0[2], A1[2], B1[2];
         issue(p_begin, A0, B0);
-        for (uint32_t i = 0;;) {                                   // the loads past the share's end (and the last trip's) fetch the pad pair
+        // One back edge, no exit in the middle: with a `break` between the halves the compiler waits for EVERY outstanding load at
+        // the loop head (s_waitcnt vmcnt(0)); this way it waits for the four older ones only, the reload stays in flight.
+        uint32_t i = 0;
+        for (; i + 4u <= T; i += 4u) {                             // loads past the share's end fetch the pad pair
             issue(p_begin + i + 2u, A1, B1);
             compute(A0, B0);
-            i += 2u;
-            if (i >= T) break;
-            issue(p_begin + i + 2u, A0, B0);
+            issue(p_begin + i + 4u, A0, B0);
             compute(A1, B1);
-            i += 2u;
-            if (i >= T) break;
         }
+        if (i < T) compute(A0, B0);                                // T is even: the last two pairs
     };
     if (T) {                                                       // wave-uniform
         if (safe) run(std::false_type{});

@@ -34,7 +34,7 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // workgroups above.
 constexpr int kPackMaxTargets = 16;
 #ifndef NBX_PACK_MAX_OPS
-#define NBX_PACK_MAX_OPS 16
+#define NBX_PACK_MAX_OPS 32
 #endif
 constexpr int kPackMaxOps = NBX_PACK_MAX_OPS;
 // Packing is used for structures whose leaves hold at most this many bodies ON AVERAGE.  Measured at N = 2^20
@@ -43,7 +43,7 @@ constexpr int kPackMaxOps = NBX_PACK_MAX_OPS;
 // leaves of 8 bodies 0.146 -> 0.194 ms and of 16 bodies 0.209 -> 0.373 ms (a leaf of 8-16 bodies fills a wave of its own at
 // 4-8 lanes per target and shares its staged sources among them; side by side every lane loads its own).
 #ifndef NBX_PACK_MEAN_LEAF
-#define NBX_PACK_MEAN_LEAF 6   /* A/B builds raise it to pack larger leaves too */
+#define NBX_PACK_MEAN_LEAF 8   /* A/B builds raise it to pack larger leaves too */
 #endif
 constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
 constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
@@ -219,7 +219,8 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     {
         size_t nonempty_leaves = 0;
         for (size_t l = 0; l < n_leaves; ++l) nonempty_leaves += leaf_offsets[l + 1] > leaf_offsets[l];
-        pack_small_leaves = pack_small_leaves && nonempty_leaves && slots <= (size_t)kPackMeanLeaf * nonempty_leaves;
+        pack_small_leaves = pack_small_leaves && nonempty_leaves && slots <= (size_t)kPackMeanLeaf * nonempty_leaves &&
+                            unit_off[n_leaves] < (1u << 28) - 2u;   // the packed kernel addresses units by 32-bit byte offsets
     }
     // packed waves.  A lane holds two targets, so a leaf of c bodies takes ceil(c / 2) lanes per lane group.  Leaves are packed
     // with leaves of their own SIZE CLASS -- 1-2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2 lane groups), 9-16 bodies on 16 lanes

@@ -18,7 +18,7 @@ from oracle_lib import Oracle, assert_force_parity  # noqa: E402
 def one_case(rng, oracle, k):
     dim = int(rng.choice([2, 3]))
     regime = rng.choice(["tiny", "small", "medium", "big", "mixed"])
-    # tiny: a few bodies per leaf and many leaves -- the structures the planner PACKS, several leaves to a wave (mean leaf <= 6)
+    # tiny: a few bodies per leaf and many leaves -- the structures the planner PACKS, several leaves to a wave (mean leaf <= 8)
     n_leaves = int(rng.integers(1, 300)) if regime == "tiny" else int(rng.integers(1, 40))
     hi = {"tiny": int(rng.integers(2, 11)), "small": 20, "medium": 80, "big": 300, "mixed": 200}[regime]
     sizes = rng.integers(0, hi, n_leaves)

@@ -105,7 +105,7 @@ def _check(plan, lo, lb, so, ss):
     for op_lo, op_n, key, _, f0, c0, f1, c1 in blocks.astype(np.int64):
         assert c0 <= 64 and c1 <= 64 and c0 + c1 >= 1 and (waves == 2 or c1 == 0)
         l = leaf_of_unit[f0 if c0 else f1]
-        assert sizes[l] > 16 or n_ops_of_leaf(op_off, l) > 16 or not (nonempty.sum() <= 6 * nonempty.size)   # tiny-leaf structures pack those
+        assert sizes[l] > 16 or n_ops_of_leaf(op_off, l) > 32 or not (nonempty.sum() <= 8 * nonempty.size)   # tiny-leaf structures pack those
         assert op_lo == op_off[l] and op_n == op_off[l + 1] - op_off[l]
         for f, c in ((f0, c0), (f1, c1)):
             if c:
@@ -113,7 +113,7 @@ def _check(plan, lo, lb, so, ss):
                 hit[f:f + c] += 1
         if c0 and c1:
             assert f1 == f0 + c0
-    # packed waves (leaves of <= 16 bodies with <= 16 runs): K = 64 / w leaves side by side, each on its own w lanes
+    # packed waves (leaves of <= 16 bodies with <= 32 runs): K = 64 / w leaves side by side, each on its own w lanes
     subs, packs = plan["pack_subs"].astype(np.int64), plan["pack_blocks"].astype(np.int64)
     n_ops_of = np.diff(op_off.astype(np.int64))
     seen_sub = np.zeros(subs.shape[0], dtype=np.int64)
@@ -121,7 +121,7 @@ def _check(plan, lo, lb, so, ss):
         assert w in (8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
-        assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 16).all()
+        assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 32).all()
         # leaves share a wave with leaves of their size class (a lane holds two targets): 1-2, 3-4, 5-8 bodies on 8 lanes
         # (8, 4, 2 lane groups), 9-16 bodies on 16 lanes (2 groups)
         cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 8 else 3
@@ -140,11 +140,11 @@ def _check(plan, lo, lb, so, ss):
     assert (seen_sub == 1).all()
     if packs.shape[0] > 1:
         assert (np.diff(packs[:, 4]) <= 0).all()                # longest first
-    # a leaf is packed exactly when the structure's leaves are tiny on average (<= 6 bodies), it is small and its list short
+    # a leaf is packed exactly when the structure's leaves are small on average (<= 8 bodies), it is small and its list short
     packed_leaves = set(leaf_of_unit[subs[:, 2]].tolist()) if subs.shape[0] else set()
-    tiny = bool(nonempty.size) and nonempty.sum() <= 6 * nonempty.size
+    tiny = bool(nonempty.size) and nonempty.sum() <= 8 * nonempty.size
     for l in range(sizes.size):
-        assert (l in packed_leaves) == bool(tiny and 1 <= sizes[l] <= 16 and n_ops_of[l] <= 16), l
+        assert (l in packed_leaves) == bool(tiny and 1 <= sizes[l] <= 16 and n_ops_of[l] <= 32), l
     assert (hit == (pslot_body != PAD)).all()
     # launch order: longest first (1024 duration classes)
     key = blocks[:, 2].astype(np.int64)
