@@ -377,7 +377,7 @@ constexpr int kPackMaxSubs = 8;                  // w >= 8
 #endif
 template <int D, int LAW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAVES, 8))) void leaf_pack_kernel(LeafPackArgs a) {
-    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps], op_base[kPackMaxSubs][kPackMaxOps];
+    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps + 1], op_base[kPackMaxSubs][kPackMaxOps + 1];   // + the pad run behind a leaf's last
     __shared__ double osum[3][128];                                // [component][second target? 64 : 0][lane]
     const unsigned lane = threadIdx.x;
     const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
@@ -403,37 +403,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     auto close = [](const float x, const float y, const float z) { return !(__builtin_fabsf(x) >= kCloseCoord && __builtin_fabsf(y) >= kCloseCoord && (D == 2 || __builtin_fabsf(z) >= kCloseCoord)); };
     const bool in_close_set = my.count != 0u && (close(ix, iy, iz) || close(jx, jy, jz));
     const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && *a.max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
-    // this leaf's copy runs and the length of its stream
+    // this leaf's copy runs, as {end of the run in the stream, byte offset of the run's first unit minus 16 x its stream position}
+    // (32-bit byte offsets from a scalar base: the plan packs nothing beyond 2^28 units), and behind the last one the PAD RUN:
+    // it never ends, and every position of it is the launch's pad pair (its positions are masked to zero)
     for (unsigned k = lw; k < my.op_n; k += w) {
         const CopyOp o = a.ops[my.op_lo + k];
         op_end[sub][k] = o.end;
-        op_base[sub][k] = o.base;
+        op_base[sub][k] = o.base << 4;
     }
-    const uint32_t my_pairs = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end >> 1 : 0u;
-    const uint32_t p_begin = g * T;
-    const uint32_t p_stop = !valid ? 0u : (p_begin + T < my_pairs ? p_begin + T : my_pairs);
-    const uint32_t pad_unit = a.pslots;
+    if (lw == 0u) { op_end[sub][my.op_n] = 0xffffffffu; op_base[sub][my.op_n] = a.pslots << 4; }
     Sums<D> S0, S1;
     for (int c = 0; c < 3; ++c) { osum[c][lane] = 0.0; osum[c][64u + lane] = 0.0; }
     S0.o = &osum[0][lane];
     S1.o = &osum[0][64u + lane];
     S0.stride = S1.stride = 128u;
     __syncthreads();                                               // the run tables (one wave: cheap)
-    unsigned k = 0;                                                // this lane's cursor in its leaf's runs; only ever moves forward
-    uint32_t run_end = 0u, run_base = 0u;                          // the run it is in
-    auto unit_of = [&](const uint32_t p) -> uint32_t {             // where pair p of this lane's share lies
-        uint32_t u = pad_unit;
-        if (p < p_stop) {
-            const uint32_t v = 2u * p;
-            while (v >= run_end) { run_end = op_end[sub][k]; run_base = op_base[sub][k]; ++k; }
-            u = run_base + v;                                      // a run is whole leaves, a leaf whole pairs: both units of the pair
+    // Lane group g walks stream positions [2 g T, 2 (g + 1) T) of its leaf.  The cursor k only ever moves forward; the run it is in
+    // sits in registers.  A lane without a target starts (and stays) in a pad run of its own.
+    const uint32_t v_begin = 2u * g * T;
+    unsigned k = 0;
+    uint32_t run_end = valid ? 0u : 0xffffffffu, run_off = a.pslots << 4, run_mask = 0u;
+    auto offset_of = [&](const uint32_t v) -> uint32_t {           // byte offset of the pair at stream position v (even)
+        while (v >= run_end) {                                     // rare (a run is ~3 leaves); the pad run ends the search
+            run_end = op_end[sub][k];
+            run_off = op_base[sub][k];
+            run_mask = k == my.op_n ? 0u : 0xffffffffu;
+            ++k;
         }
-        return u;
+        return ((v & run_mask) << 4) + run_off;                    // a run is whole leaves, a leaf whole pairs: both units of the pair
     };
-    // 32-bit byte offsets from a scalar base (the plan packs nothing beyond 2^28 units): one shift per pair, the second unit at an immediate offset
     const char* __restrict__ const xp_bytes = reinterpret_cast<const char*>(a.xp);
-    auto issue = [&](const uint32_t p, float4 (&A)[2], float4 (&B)[2]) {
-        const uint32_t o0 = unit_of(p) << 4, o1 = unit_of(p + 1u) << 4;
+    auto issue = [&](const uint32_t i, float4 (&A)[2], float4 (&B)[2]) {   // pairs i and i + 1 of this lane's share
+        const uint32_t v = v_begin + 2u * i;
+        const uint32_t o0 = offset_of(v), o1 = offset_of(v + 2u);
         const float4* __restrict__ s0 = reinterpret_cast<const float4*>(xp_bytes + o0);
         const float4* __restrict__ s1 = reinterpret_cast<const float4*>(xp_bytes + o1);
         A[0] = s0[0]; B[0] = s0[1];
@@ -461,14 +463,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
             S0.pending += 4u;
         };
         float4 A0[2], B0[2], A1[2], B1[2];
-        issue(p_begin, A0, B0);
+        issue(0u, A0, B0);
         // One back edge, no exit in the middle: with a `break` between the halves the compiler waits for EVERY outstanding load at
         // the loop head (s_waitcnt vmcnt(0)); this way it waits for the four older ones only, the reload stays in flight.
         uint32_t i = 0;
-        for (; i + 4u <= T; i += 4u) {                             // loads past the share's end fetch the pad pair
-            issue(p_begin + i + 2u, A1, B1);
+        for (; i + 4u <= T; i += 4u) {                             // loads past the share's end fetch the next share's pairs or the pad pair: not used
+            issue(i + 2u, A1, B1);
             compute(A0, B0);
-            issue(p_begin + i + 4u, A0, B0);
+            issue(i + 4u, A0, B0);
             compute(A1, B1);
         }
         if (i < T) compute(A0, B0);                                // T is even: the last two pairs
