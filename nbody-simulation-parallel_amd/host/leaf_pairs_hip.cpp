@@ -93,6 +93,11 @@ void LeafPairSimulationHip<D>::step(LeafLaw law, double G, double dt, int nsteps
     }
 }
 template <int D>
+void LeafPairSimulationHip<D>::synchronize() {
+    const int rc = nbx_ctx_synchronize(ctx_);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::synchronize", rc);
+}
+template <int D>
 void LeafPairSimulationHip<D>::download(std::vector<Body<D>>& bodies) {
     if (bodies.size() != n_) throw std::runtime_error("LeafPairSimulationHip::download: body count differs");
     const int rc = nbx_ctx_download_bodies(ctx_, bodies.data(), sizeof(Body<D>));

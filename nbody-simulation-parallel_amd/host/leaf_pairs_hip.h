@@ -50,6 +50,7 @@ public:
     void evaluate(LeafLaw law, double G);
     // nsteps x { leaf sums; update_body_velocities; update_body_positions } (methods.cpp:425-450) on the device, asynchronous
     void step(LeafLaw law, double G, double dt, int nsteps);
+    void synchronize();   // waits for the steps queued so far
     void download(std::vector<Body<D>>& bodies);
     float single_launch_ms(LeafLaw law, double G);      // pair kernel of one evaluation
     float back_to_back_ms(LeafLaw law, int reps);      // measurement: mean of the second half of `reps` launches in a row
