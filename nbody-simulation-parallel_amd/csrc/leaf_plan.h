@@ -3,9 +3,11 @@
 // invariants without a GPU.  The comment at the top of leaf_pair_kernel.hip says what each piece is for.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace nbx_leaf {
@@ -98,6 +100,8 @@ struct LeafPlan {
     std::vector<uint32_t> pslot_body;   // [pslots] body of each padded slot, 0xffffffff for a leaf's pad
     std::vector<CopyOp> ops;            // every leaf's source list as runs of consecutive units
     std::vector<uint32_t> op_off;       // [n_leaves + 1] leaf l's runs: ops[op_off[l] .. op_off[l+1])
+    std::vector<uint32_t> stream_units; // [n_leaves] length of leaf l's source stream, in 16-byte units
+    std::vector<std::vector<CopyOp>> part_ops;   // scratch of the layout's threads (kept for their capacity)
     std::vector<LeafBlock> blocks;      // the one-leaf workgroups, longest first
     int waves = kMaxWaves;              // wave64 per one-leaf workgroup of this launch
     std::vector<PackSub> pack_subs;     // packed small leaves ...
@@ -117,10 +121,24 @@ struct LeafPlan {
 //    order: eight runs of unequal durations side by side were measured 40 % SLOWER at 4-body leaves, the XCDs with the short
 //    blocks waiting for the dispatcher to get past the ones with the long blocks).
 constexpr uint32_t kXcds = 8;
+constexpr unsigned kPlanThreads = 8;            // host threads that lay out a launch's copy runs ...
+#ifndef NBX_PLAN_THREADS_FROM
+#define NBX_PLAN_THREADS_FROM 200000
+#endif
+constexpr size_t kPlanThreadsFrom = NBX_PLAN_THREADS_FROM;   // ... from this many list entries on (thread start-up: ~0.1 ms)
 #ifndef NBX_XCD_ORDER_FROM
 #define NBX_XCD_ORDER_FROM 4096
 #endif
 constexpr size_t kXcdOrderFrom = NBX_XCD_ORDER_FROM;
+// f(0) on the caller's thread, f(1) .. f(n - 1) on threads of their own
+template <class F>
+inline void run_threads(unsigned n, F f) {
+    std::thread helpers[kPlanThreads];
+    for (unsigned t = 1; t < n && t < kPlanThreads; ++t) helpers[t] = std::thread(f, t);
+    f(0u);
+    for (unsigned t = 1; t < n && t < kPlanThreads; ++t) helpers[t].join();
+}
+
 template <class Block, class Dur>
 inline void order_launch(std::vector<Block>& v, Dur dur) {
     const size_t n = v.size();
@@ -154,7 +172,15 @@ inline void order_launch(std::vector<Block>& v, Dur dur) {
 // The CSR arrays must have been validated (offsets non-decreasing from 0, every index in range).  Returns nullptr, or why the
 // structure cannot be laid out (more than 2^32 units).
 inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
-                               const uint32_t* list_sources, LeafPlan& plan, bool pack_small_leaves = true) {
+                               const uint32_t* list_sources, LeafPlan& plan, bool pack_small_leaves = true, unsigned max_threads = kPlanThreads,
+                               double* section_ms = nullptr /* [4] for tools/time_leaf_layout.cpp: slots, copy runs, workgroups, order */) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    auto section = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        if (section_ms) section_ms[k] = std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+    };
     const size_t slots = n_leaves ? leaf_offsets[n_leaves] : 0;
     const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
     // padded slots: a leaf of odd size gets one more slot, so that every leaf is a run of whole source pairs
@@ -172,39 +198,75 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     const size_t pslots = unit_off[n_leaves];
     std::vector<uint32_t>& pslot_body = plan.pslot_body;
     pslot_body.resize(pslots);                  // every slot is written below: bodies by the copy, an odd leaf's pad explicitly              // body of each padded slot, 0xffffffff for a leaf's pad
-    for (size_t l = 0; l < n_leaves; ++l) {
-        const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
-        if (c) memcpy(&pslot_body[unit_off[l]], leaf_bodies + leaf_offsets[l], (size_t)c * sizeof(uint32_t));
-        if (c & 1u) pslot_body[unit_off[l] + c] = 0xffffffffu;
-    }
-    // copy ops: the source list of each leaf as runs of consecutive units (neighbours in leaf order merged), empty leaves dropped
-    std::vector<CopyOp>& ops = plan.ops;
-    ops.clear();
-    std::vector<uint32_t>& op_off = plan.op_off;
-    op_off.resize(n_leaves + 1);
-    ops.reserve(n_list / 2 + 16);
-    for (size_t l = 0; l < n_leaves; ++l) {
-        op_off[l] = (uint32_t)ops.size();
-        uint64_t stream = 0;        // units so far
-        uint32_t run_first = 0, run_len = 0;
-        auto close_run = [&]() {
-            if (!run_len) return;
-            stream += run_len;
-            ops.push_back(CopyOp{(uint32_t)stream, run_first - (uint32_t)(stream - run_len)});
-            run_len = 0;
-        };
-        for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e) {
-            const uint32_t s = list_sources[e];
-            const uint32_t first = unit_off[s], len = unit_off[s + 1] - unit_off[s];
-            if (!len) continue;
-            if (run_len && first == run_first + run_len) run_len += len;
-            else { close_run(); run_first = first; run_len = len; }
-            if (stream + run_len > 0xfffff000ull) return "a leaf's source list names more than 2^32 bodies";
+    const unsigned n_threads = n_list >= kPlanThreadsFrom && max_threads > 1u ? (max_threads < kPlanThreads ? max_threads : kPlanThreads) : 1u;
+    run_threads(n_threads, [&](unsigned t) {
+        for (size_t l = n_leaves * t / n_threads; l < n_leaves * (t + 1u) / n_threads; ++l) {
+            const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
+            if (c) memcpy(&pslot_body[unit_off[l]], leaf_bodies + leaf_offsets[l], (size_t)c * sizeof(uint32_t));
+            if (c & 1u) pslot_body[unit_off[l] + c] = 0xffffffffu;
         }
-        close_run();
-        if (ops.size() > 0xfffffff0ull) return "source lists too long";
+    });
+    section(0);
+    // copy ops: the source list of each leaf as runs of consecutive units (neighbours in leaf order merged), empty leaves dropped.
+    // 5 ns per list entry on one core (the merge is a branch no predictor learns) and 6.7 million entries for 65,536 BVH leaves
+    // at N = 2^20: the leaves are cut into kPlanThreads ranges of equal list length, every range is laid out by a thread of its
+    // own into its own array, and the arrays are joined in leaf order -- the result does not depend on the number of threads.
+    std::vector<CopyOp>& ops = plan.ops;
+    std::vector<uint32_t>& op_off = plan.op_off;
+    std::vector<uint32_t>& stream_units = plan.stream_units;
+    op_off.resize(n_leaves + 1);
+    stream_units.resize(n_leaves);
+    if (plan.part_ops.size() < n_threads) plan.part_ops.resize(n_threads);
+    size_t cut[kPlanThreads + 1];
+    cut[0] = 0;
+    for (unsigned t = 1; t < n_threads; ++t)
+        cut[t] = (size_t)(std::lower_bound(list_offsets, list_offsets + n_leaves, (uint32_t)((uint64_t)n_list * t / n_threads)) - list_offsets);
+    cut[n_threads] = n_leaves;
+    const char* part_err[kPlanThreads] = {nullptr};
+    auto lay_out = [&](unsigned t) {
+        std::vector<CopyOp> mine;                       // this thread's own header: the scratch arrays' headers sit side by side in
+        mine.swap(plan.part_ops[t]);                    // one cache line, and push_back writes the header every time
+        struct PutBack { std::vector<CopyOp>& a; std::vector<CopyOp>& b; ~PutBack() { a.swap(b); } } put_back{mine, plan.part_ops[t]};
+        mine.clear();
+        mine.reserve((list_offsets[cut[t + 1]] - list_offsets[cut[t]]) / 2 + 16);
+        for (size_t l = cut[t]; l < cut[t + 1]; ++l) {
+            op_off[l] = (uint32_t)mine.size();          // within the range; the range's base is added below
+            uint64_t stream = 0;        // units so far
+            uint32_t run_first = 0, run_len = 0;
+            auto close_run = [&]() {
+                if (!run_len) return;
+                stream += run_len;
+                mine.push_back(CopyOp{(uint32_t)stream, run_first - (uint32_t)(stream - run_len)});
+                run_len = 0;
+            };
+            for (uint32_t e = list_offsets[l]; e < list_offsets[l + 1]; ++e) {
+                const uint32_t s = list_sources[e];
+                const uint32_t first = unit_off[s], len = unit_off[s + 1] - unit_off[s];
+                if (!len) continue;
+                if (run_len && first == run_first + run_len) run_len += len;
+                else { close_run(); run_first = first; run_len = len; }
+                if (stream + run_len > 0xfffff000ull) { part_err[t] = "a leaf's source list names more than 2^32 bodies"; return; }
+            }
+            close_run();
+            stream_units[l] = (uint32_t)stream;
+        }
+    };
+    run_threads(n_threads, lay_out);
+    size_t base[kPlanThreads + 1];
+    base[0] = 0;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        if (part_err[t]) return part_err[t];
+        base[t + 1] = base[t] + plan.part_ops[t].size();
     }
+    if (base[n_threads] > 0xfffffff0ull) return "source lists too long";
+    ops.resize(base[n_threads]);
+    auto join_range = [&](unsigned t) {
+        if (!plan.part_ops[t].empty()) memcpy(ops.data() + base[t], plan.part_ops[t].data(), plan.part_ops[t].size() * sizeof(CopyOp));
+        if (base[t]) for (size_t l = cut[t]; l < cut[t + 1]; ++l) op_off[l] += (uint32_t)base[t];
+    };
+    run_threads(n_threads, join_range);
     op_off[n_leaves] = (uint32_t)ops.size();
+    section(1);
     // workgroups.  Leaves of the size the reference's FMM keeps (tens of bodies, methods.h:26): two waves, 128 targets of a leaf at
     // most, cut into the two waves' pieces.  Small leaves (the BVH's 16 bodies and below): one wave per workgroup and no cut -- a
     // leaf of 16 fills a wave at 4 lanes per target, and a workgroup barrier costs more than two waves sharing ~100 staged bodies save.
@@ -237,36 +299,54 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
         if (pack_small_leaves && c >= 1u && c <= (uint32_t)kPackMaxTargets && op_off[l + 1] - op_off[l] <= (uint32_t)kPackMaxOps)
             packable[size_class(c)].push_back((uint32_t)l);
     }
-    auto stream_of = [&](uint32_t l) -> uint32_t { const uint32_t n_ops = op_off[l + 1] - op_off[l]; return n_ops ? ops[op_off[l] + n_ops - 1].end : 0u; };
+    // Where a class's waves and leaves go is known from the class sizes alone, so the classes' windows (eight waves' leaves each) are
+    // laid out by the layout's threads, every window on its own.
+    // A wave runs as long as its longest leaf: within every window (neighbouring leaves: the locality stays) the leaves are taken
+    // longest stream first, so that a wave's leaves are of nearly one length (a 27-cell neighbourhood of ~4.5-body cells: the longest
+    // of 8 random ones is 12 % above the mean, of 8 consecutive ones of a sorted 64 2 %).
+    size_t sub_base[5] = {0}, pack_base[5] = {0}, win_base[5] = {0};
     for (int k = 0; k < 4; ++k) {
-        const uint32_t w = k == 3 ? 16u : 8u, per_wave = 64u / w;
-        const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : 2u;
-        // a wave runs as long as its longest leaf: within every window of eight waves' leaves (neighbours: the locality stays) the
-        // leaves are taken longest stream first, so that a wave's leaves are of nearly one length (a 27-cell neighbourhood of
-        // ~4.5-body cells: the longest of 8 random ones is 12 % above the mean, of 8 consecutive ones of a sorted 64 2 %)
-        for (size_t i = 0; i < packable[k].size(); i += 8u * per_wave) {
-            const size_t e = i + 8u * per_wave < packable[k].size() ? i + 8u * per_wave : packable[k].size();
-            std::stable_sort(packable[k].begin() + (ptrdiff_t)i, packable[k].begin() + (ptrdiff_t)e, [&](uint32_t x, uint32_t y) { return stream_of(x) > stream_of(y); });
-        }
-        for (size_t i = 0; i < packable[k].size(); i += per_wave) {
-            PackBlock b{};
-            b.sub_lo = (uint32_t)subs.size();
-            b.w = w; b.w_log2 = k == 3 ? 4u : 3u; b.P = P;
-            uint32_t longest = 0;
-            for (size_t j = i; j < packable[k].size() && j < i + per_wave; ++j) {
-                const uint32_t l = packable[k][j];
-                const uint32_t n_ops = op_off[l + 1] - op_off[l];
-                const uint32_t stream = n_ops ? ops[op_off[l] + n_ops - 1].end : 0u;
-                subs.push_back(PackSub{op_off[l], n_ops, unit_off[l], leaf_offsets[l + 1] - leaf_offsets[l]});
-                ++b.n_sub;
-                if (stream > longest) longest = stream;
-            }
-            const uint32_t per_group = ((longest >> 1) + P - 1u) / P;   // streams are whole pairs (every leaf is padded to an even size)
-            b.trips = (per_group + (uint32_t)kPackPairsPerTrip - 1u) / (uint32_t)kPackPairsPerTrip * (uint32_t)kPackPairsPerTrip;
-            b.longest = longest;
-            packs.push_back(b);
-        }
+        const size_t per_wave = k == 3 ? 4u : 8u;
+        sub_base[k + 1] = sub_base[k] + packable[k].size();
+        pack_base[k + 1] = pack_base[k] + (packable[k].size() + per_wave - 1u) / per_wave;
+        win_base[k + 1] = win_base[k] + (packable[k].size() + 8u * per_wave - 1u) / (8u * per_wave);
     }
+    subs.resize(sub_base[4]);
+    packs.resize(pack_base[4]);
+    const unsigned pack_threads = win_base[4] >= 64u ? n_threads : 1u;
+    auto pack_windows = [&](unsigned t) {
+        const size_t w_lo = win_base[4] * t / pack_threads, w_hi = win_base[4] * (t + 1u) / pack_threads;
+        for (size_t wi = w_lo; wi < w_hi; ++wi) {
+            int k = 0;
+            while (wi >= win_base[k + 1]) ++k;
+            const uint32_t w = k == 3 ? 16u : 8u, per_wave = 64u / w;
+            const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : 2u;
+            std::vector<uint32_t>& leaves_k = packable[k];
+            const size_t i = (wi - win_base[k]) * 8u * per_wave;
+            const size_t e = i + 8u * per_wave < leaves_k.size() ? i + 8u * per_wave : leaves_k.size();
+            uint64_t key[64];                           // longest first, leaf order among equals: one integer sort per window
+            for (size_t j = i; j < e; ++j) key[j - i] = ((uint64_t)(0xffffffffu - stream_units[leaves_k[j]]) << 32) | leaves_k[j];
+            std::sort(key, key + (e - i));
+            for (size_t j = i; j < e; ++j) leaves_k[j] = (uint32_t)key[j - i];
+            for (size_t i0 = i; i0 < e; i0 += per_wave) {
+                PackBlock b{};
+                b.sub_lo = (uint32_t)(sub_base[k] + i0);
+                b.w = w; b.w_log2 = k == 3 ? 4u : 3u; b.P = P;
+                uint32_t longest = 0;
+                for (size_t j = i0; j < e && j < i0 + per_wave; ++j) {
+                    const uint32_t l = leaves_k[j];
+                    subs[sub_base[k] + j] = PackSub{op_off[l], op_off[l + 1] - op_off[l], unit_off[l], leaf_offsets[l + 1] - leaf_offsets[l]};
+                    ++b.n_sub;
+                    if (stream_units[l] > longest) longest = stream_units[l];
+                }
+                const uint32_t per_group = ((longest >> 1) + P - 1u) / P;   // streams are whole pairs (every leaf is padded to an even size)
+                b.trips = (per_group + (uint32_t)kPackPairsPerTrip - 1u) / (uint32_t)kPackPairsPerTrip * (uint32_t)kPackPairsPerTrip;
+                b.longest = longest;
+                packs[pack_base[k] + i0 / per_wave] = b;
+            }
+        }
+    };
+    run_threads(pack_threads, pack_windows);
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (!c) continue;
@@ -292,8 +372,10 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             f += share;
         }
     }
+    section(2);
     order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips; });
     order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
+    section(3);
 
     return nullptr;
 }

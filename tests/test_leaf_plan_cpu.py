@@ -39,6 +39,12 @@ def planner(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
+def planner_threads(tmp_path_factory):
+    """The same planner with the layout's threads switched on from 64 list entries (the library: from 200,000)."""
+    return _build_planner(tmp_path_factory, "leaf_plan_threads", "-DNBX_PLAN_THREADS_FROM=64", "-pthread")
+
+
+@pytest.fixture(scope="module")
 def planner_xcd(tmp_path_factory):
     """The same planner with the XCD-aware order switched on from 16 workgroups (the library: from 4,096), so that structures of test size reach it."""
     return _build_planner(tmp_path_factory, "leaf_plan_xcd", "-DNBX_XCD_ORDER_FROM=16")
@@ -234,3 +240,19 @@ def test_workgroups_of_a_class_are_dealt_to_the_xcds_in_runs(planner_xcd, tmp_pa
     # packed waves of one duration class can belong to different size classes (built class by class, each in leaf order): the runs are
     # consecutive in BUILD order, which is the order of their first sub-leaf
     assert _check_xcd_runs(packs[:, 4], packs[:, 0]) >= 2
+
+
+def test_the_layout_does_not_depend_on_the_number_of_threads(planner, planner_threads, tmp_path):
+    """csrc/leaf_plan.h lays the copy runs and the packed waves out on up to 8 threads (ranges of leaves of equal list length; windows
+    of packed leaves); every array of the plan must come out as from one thread.  (Under ASan + UBSan, like the rest of this file.)"""
+    rng = np.random.default_rng(9)
+    for seed, sizes, list_len in ((21, rng.integers(0, 12, 3000).tolist(), lambda t: [3, 9, 27, 0, 14][t % 5]),
+                                  (22, rng.integers(1, 90, 500).tolist(), lambda t: [5, 40, 1][t % 3]),
+                                  (23, [4] * 70 + [0] * 5 + [9] * 30, lambda t: 9)):
+        lo, lb, so, ss = _structure(seed, sizes, list_len)
+        da, db = tmp_path / f"one{seed}", tmp_path / f"many{seed}"
+        da.mkdir(); db.mkdir()
+        one, many = planner(str(da), lo, lb, so, ss), planner_threads(str(db), lo, lb, so, ss)
+        _check(many, lo, lb, so, ss)
+        for k in one:
+            assert np.array_equal(one[k], many[k]), k

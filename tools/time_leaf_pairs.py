@@ -1,6 +1,7 @@
 """Near-field (leaf-pair) direct sums at FMM-like sizes: N bodies in a uniform grid of leaves (2^(3*level) cells), every
 leaf against its 27-cell neighbourhood, through nbx_leaf_pair_forces (one-shot) and nbx_leaf_plan_* (resident); prints the kernel's own time per law.
-    python tools/time_leaf_pairs.py [N] [level | bvh<K>] [box]
+    python tools/time_leaf_pairs.py [N] [level | bvh<K>] [box] [--dump DIR]
+--dump DIR: write the structure's CSR arrays as raw uint32 files (for tools/time_leaf_layout.cpp) and stop.
 level: uniform grid of 2^level cells per axis with 27-cell lists (5: 32 bodies per leaf at N = 2^20, 6: 4 bodies per leaf);
 bvh<K> (e.g. bvh16): median-split leaves of at most K bodies, the reference BVH's own (bvh.cpp:34-73, methods.h:57), with
 box-distance near-field lists (leaves.median_split_leaves).
@@ -11,6 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nbody_amd as nbx
 
+dump_dir = None
+if "--dump" in sys.argv:
+    k = sys.argv.index("--dump")
+    dump_dir = sys.argv[k + 1]
+    del sys.argv[k:k + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 shape = sys.argv[2] if len(sys.argv) > 2 else "5"
 b = nbx.uniform_bodies(n, 3, 5)
@@ -22,6 +28,12 @@ if shape.startswith("bvh"):
 else:
     leaves = nbx.leaves.uniform_grid_leaves(b, 3, int(shape))
 print(f"leaves '{shape}' built on the host in {time.perf_counter() - t_build:.1f} s (not part of any timing below)", flush=True)
+if dump_dir:
+    os.makedirs(dump_dir, exist_ok=True)
+    for name, a in zip(("leaf_offsets", "leaf_bodies", "list_offsets", "list_sources"), leaves):
+        np.asarray(a, dtype=np.uint32).tofile(os.path.join(dump_dir, name + ".u32"))
+    print(f"arrays written to {dump_dir}")
+    sys.exit(0)
 lo, _, so, ss = leaves
 sizes = np.diff(lo).astype(np.int64)
 src = np.add.reduceat(sizes[ss], so[:-1])          # bodies on each leaf's list (every list here is non-empty)
@@ -50,6 +62,13 @@ for law, name in LAWS:
     print(f"law {name:9s}: one-shot call: kernel, one launch after the call's host work and copies (clocks at ~2.05 GHz) {rate(cold[name][0])};  "
           f"whole call (validation, layout, H2D, gather, kernel, scatter, D2H) {cold[name][1]:.2f} ms", flush=True)
 # the resident plan (nbx_leaf_plan_*): the structure validated, laid out and uploaded once, bodies resident in a context
+# what a tree code that rebuilds its tree every step pays per step: a new plan for the new structure (validation, layout, uploads)
+remake = 1e30
+for _ in range(3):
+    t0 = time.perf_counter()
+    with nbx.LeafPlan(n, 3, *leaves):
+        remake = min(remake, (time.perf_counter() - t0) * 1e3)
+print(f"plan alone (nbx_leaf_plan_create for a structure of this shape, best of 3; the previous plan destroyed first): {remake:.2f} ms", flush=True)
 t0 = time.perf_counter()
 plan = nbx.LeafPlan(n, 3, *leaves)
 ctx = nbx.Context(n, 3)
