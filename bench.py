@@ -158,6 +158,26 @@ def leaf_pair_roofline(device):
         single = min(plan.forces_ctx(ctx, law, fetch=False, timed=True) for _ in range(3))
         warm = plan.time_kernel(law, 300)
     tflops = lambda ms: pairs * 20.0 / (ms * 1e-3) / 1e12
+    # the same measurement at the leaf sizes the reference's trees make: its BVH's 16-body leaves, what a 16-body
+    # cap makes of smaller nodes (8), and 4-body cells; structures of small leaves go through the packed kernel (leaf_pack_kernel)
+    by_size = []
+    for label, build in (("median-split leaves of 16 bodies (the reference BVH's cap, methods.h:57), box-distance near-field lists", lambda: nbx.leaves.median_split_leaves(b, 3, 16, reach=0.5)),
+                         ("median-split leaves of 8 bodies", lambda: nbx.leaves.median_split_leaves(b, 3, 8, reach=0.5)),
+                         ("64^3 grid cells of ~4 bodies, 27-cell lists", lambda: nbx.leaves.uniform_grid_leaves(b, 3, 6))):
+        sl = build()
+        ssz = np.diff(sl[0]).astype(np.int64)
+        sp = int((ssz * np.add.reduceat(ssz[sl[3]], sl[2][:-1])).sum())
+        with nbx.LeafPlan(n, 3, *sl, device=device) as plan, nbx.Context(n, 3, device=device) as ctx:
+            ctx.upload(b)
+            ctx.synchronize()
+            plan.forces_ctx(ctx, law, fetch=False)
+            one = min(plan.forces_ctx(ctx, law, fetch=False, timed=True) for _ in range(3))
+            many = plan.time_kernel(law, 300)
+            slots, runs, groups, waves = plan.info()
+        by_size.append({"workload": f"N={n}, {ssz.size} {label} (mean {ssz.mean():.1f})", "pair_terms_per_launch": sp,
+                        "kernel": "leaf_pack_kernel<3, NBX_LAW_TREE_LEAF> (several leaves to a wave)" if ssz.mean() <= 8.0 else "leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 1>",
+                        "workgroups": int(groups), "kernel_ms": one, "frac": sp * 20.0 / (one * 1e-3) / 1e12 / 157.3,
+                        "back_to_back": {"kernel_ms": many, "frac": sp * 20.0 / (many * 1e-3) / 1e12 / 157.3}})
     return {"kernel": "leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 2>", "workload": f"N={n}, {sizes.size} grid leaves (mean {sizes.mean():.1f} bodies), 27-cell lists",
             "entry": "nbx_leaf_plan_forces_ctx (resident plan + resident bodies)", "law_pin": "TREE_LEAF: pinned on the reference's own BVH leaves (tests/golden/bvh_leaves_*.npz)",
             "pair_terms_per_launch": pairs, "flop_per_pair_term": 20, "bound": "mfma",
@@ -167,7 +187,8 @@ def leaf_pair_roofline(device):
             "evaluation_wall_ms_median": float(np.median(walls)),
             "first_launch_from_idle_clocks": {"kernel_ms": cold, "achieved": tflops(cold), "frac": tflops(cold) / 157.3},
             "back_to_back": {"kernel_ms": warm, "achieved": tflops(warm), "frac": tflops(warm) / 157.3,
-                             "means": "mean of launches 151-300 of 300 back to back (nbx_leaf_plan_time_kernel): clocks up"}}
+                             "means": "mean of launches 151-300 of 300 back to back (nbx_leaf_plan_time_kernel): clocks up"},
+            "at_the_reference_trees_leaf_sizes": by_size}
 
 
 def _norm(a):

@@ -31,30 +31,27 @@ def uniform_grid_leaves(bodies: np.ndarray, dim: int, depth: int):
     keys, first = np.unique(key[order], return_index=True)
     leaf_offsets = np.append(first, n).astype(np.uint32)
     leaf_bodies = order.astype(np.uint32)
-    index_of = {int(k): i for i, k in enumerate(keys)}
-    # decode the cell coordinates of every leaf and look its 3^dim neighbours up
+    # decode the cell coordinates of every leaf and look its 3^dim neighbours up (keys is sorted: a binary search per neighbour cell)
     coords = np.zeros((keys.size, dim), dtype=np.int64)
     rest = keys.copy()
     for d in range(dim - 1, -1, -1):
         coords[:, d] = rest % g
         rest //= g
     offs = np.stack(np.meshgrid(*[np.arange(-1, 2)] * dim, indexing="ij"), -1).reshape(-1, dim)
-    offs = offs[np.any(offs != 0, axis=1)]
-    list_offsets = [0]
-    list_sources = []
-    for l in range(keys.size):
-        list_sources.append(l)                       # own bodies first (fmm_parlay.cpp:973-974)
-        for o in offs:
-            c = coords[l] + o
-            if np.any(c < 0) or np.any(c >= g):
-                continue
-            k = 0
-            for d in range(dim):
-                k = k * g + int(c[d])
-            j = index_of.get(k)
-            if j is not None:
-                list_sources.append(j)
-        list_offsets.append(len(list_sources))
+    offs = np.concatenate([np.zeros((1, dim), dtype=offs.dtype), offs[np.any(offs != 0, axis=1)]])   # own bodies first (fmm_parlay.cpp:973-974)
+    found = np.full((keys.size, offs.shape[0]), -1, dtype=np.int64)
+    for c, o in enumerate(offs):
+        nb = coords + o
+        inside = np.all((nb >= 0) & (nb < g), axis=1)
+        k = np.zeros(keys.size, dtype=np.int64)
+        for d in range(dim):
+            k = k * g + nb[:, d]
+        at = np.minimum(np.searchsorted(keys, k), keys.size - 1)
+        hit = inside & (keys[at] == k)
+        found[hit, c] = at[hit]
+    present = found >= 0
+    list_offsets = np.concatenate([[0], np.cumsum(present.sum(axis=1))])
+    list_sources = found[present]                                    # row-major: every leaf's cells in the order of `offs`
     return (leaf_offsets, leaf_bodies, np.asarray(list_offsets, dtype=np.uint32), np.asarray(list_sources, dtype=np.uint32))
 
 
@@ -81,41 +78,67 @@ def median_split_leaves(bodies: np.ndarray, dim: int, max_leaf_size: int = 16, r
     if n == 0:
         z = np.zeros(1, dtype=np.uint32)
         return z, np.zeros(0, dtype=np.uint32), z.copy(), np.zeros(0, dtype=np.uint32)
+    # level by level: the nodes of a level have at most two different sizes (a node of s bodies splits into s // 2 and s - s // 2),
+    # and all nodes of one size are split in one batched call
     order = np.arange(n)
-    leaves = []
-    stack = [(0, n)]
-    while stack:
-        lo, hi = stack.pop()
-        if hi - lo <= max_leaf_size:
-            leaves.append((lo, hi))
-            continue
-        idx = order[lo:hi]
-        p = pos[idx]
-        axis = int(np.argmax(p.max(axis=0) - p.min(axis=0)))
-        mid = (hi - lo) // 2
-        part = np.argpartition(p[:, axis], mid)
-        order[lo:hi] = idx[part]
-        stack.append((lo + mid, hi))      # popped second: the lower half's subtree comes out first
-        stack.append((lo, lo + mid))
-    leaves.sort()
-    leaf_offsets = np.array([l for l, _ in leaves] + [n], dtype=np.uint32)
-    nl = len(leaves)
-    bmin = np.array([pos[order[l:h]].min(axis=0) for l, h in leaves])
-    bmax = np.array([pos[order[l:h]].max(axis=0) for l, h in leaves])
+    nodes = np.array([[0, n]], dtype=np.int64)              # [lo, hi) of the current level's nodes, in tree order
+    done = []
+    while nodes.size:
+        size = nodes[:, 1] - nodes[:, 0]
+        leaf = size <= max_leaf_size
+        done.append(nodes[leaf])
+        nodes = nodes[~leaf]
+        size = size[~leaf]
+        nxt = np.empty((2 * nodes.shape[0], 2), dtype=np.int64)
+        for s_ in np.unique(size):
+            sel = np.nonzero(size == s_)[0]
+            at = nodes[sel, 0][:, None] + np.arange(s_)[None, :]          # [k, s] positions in `order`
+            idx = order[at]
+            p = pos[idx]                                                # [k, s, dim]
+            axis = np.argmax(p.max(axis=1) - p.min(axis=1), axis=1)     # longest axis of every node's box
+            val = np.take_along_axis(p, axis[:, None, None], axis=2)[:, :, 0]
+            mid = int(s_) // 2
+            part = np.argpartition(val, mid, axis=1)
+            order[at] = np.take_along_axis(idx, part, axis=1)
+            nxt[2 * sel, 0] = nodes[sel, 0]; nxt[2 * sel, 1] = nodes[sel, 0] + mid          # lower half first
+            nxt[2 * sel + 1, 0] = nodes[sel, 0] + mid; nxt[2 * sel + 1, 1] = nodes[sel, 1]
+        nodes = nxt
+    leaves = np.concatenate(done)
+    leaves = leaves[np.argsort(leaves[:, 0], kind="stable")]
+    leaf_offsets = np.append(leaves[:, 0], n).astype(np.uint32)
+    nl = leaves.shape[0]
+    sorted_pos = pos[order]
+    bmin = np.minimum.reduceat(sorted_pos, leaves[:, 0], axis=0)
+    bmax = np.maximum.reduceat(sorted_pos, leaves[:, 0], axis=0)
     diag = np.linalg.norm(bmax - bmin, axis=1)
     centre = 0.5 * (bmin + bmax)
     from scipy.spatial import cKDTree
-    tree = cKDTree(centre)
-    # candidates by centre distance (a superset), then the exact box-to-box distance
+    # candidates by centre distance (a superset: box gap >= centre distance - the two half diagonals), then the exact box-to-box
+    # distance.  Leaves are put into buckets of like diagonal (ratio 1.25) and every pair of buckets is queried once with the
+    # radius its largest members need -- the result is arrays (a ball query per leaf returns Python lists: slow for a million bodies)
     half = 0.5 * diag
-    cand = tree.query_ball_point(centre, r=(1.0 + reach) * diag + half.max())
-    list_offsets, list_sources = [0], []
-    for l in range(nl):
-        c = np.asarray(cand[l], dtype=np.int64)
-        c = c[c != l]
-        gap = np.maximum(0.0, np.maximum(bmin[c] - bmax[l], bmin[l] - bmax[c]))
-        near = c[np.linalg.norm(gap, axis=1) <= reach * diag[l]]
-        list_sources.append(l)
-        list_sources.extend(np.sort(near).tolist())
-        list_offsets.append(len(list_sources))
+    d_min = max(float(diag.min()), 1e-300 + float(diag.max()) * 1e-6)
+    bucket = np.floor(np.log(np.maximum(diag, d_min) / d_min) / np.log(1.25)).astype(np.int64)
+    ids_of = [np.nonzero(bucket == b_)[0] for b_ in np.unique(bucket)]
+    trees = [cKDTree(centre[ids]) for ids in ids_of]
+    rows_parts, c_parts = [np.zeros(0, dtype=np.int64)], [np.zeros(0, dtype=np.int64)]
+    for ia, ta in zip(ids_of, trees):
+        for ib, tb in zip(ids_of, trees):
+            found = ta.sparse_distance_matrix(tb, float((0.5 + reach) * diag[ia].max() + half[ib].max()), output_type="ndarray")
+            rows_parts.append(ia[found["i"]])
+            c_parts.append(ib[found["j"]])
+    rows, c = np.concatenate(rows_parts), np.concatenate(c_parts)
+    other = c != rows
+    rows, c = rows[other], c[other]
+    gap = np.maximum(0.0, np.maximum(bmin[c] - bmax[rows], bmin[rows] - bmax[c]))
+    near = np.sqrt((gap * gap).sum(axis=1)) <= reach * diag[rows]
+    rows, c = rows[near], c[near]
+    by_leaf = np.lexsort((c, rows))                          # every leaf's neighbours in ascending order
+    rows, c = rows[by_leaf], c[by_leaf]
+    counts = np.bincount(rows, minlength=nl)
+    list_offsets = np.concatenate([[0], np.cumsum(counts + 1)])
+    list_sources = np.empty(int(list_offsets[-1]), dtype=np.int64)
+    list_sources[list_offsets[:-1]] = np.arange(nl)          # the leaf itself first
+    rank = np.arange(rows.size) - np.repeat(np.cumsum(counts) - counts, counts)
+    list_sources[list_offsets[rows] + 1 + rank] = c
     return (leaf_offsets, order.astype(np.uint32), np.asarray(list_offsets, dtype=np.uint32), np.asarray(list_sources, dtype=np.uint32))
