@@ -717,7 +717,8 @@ int validate_csr(size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bo
         if (leaf_offsets[l + 1] < leaf_offsets[l] || list_offsets[l + 1] < list_offsets[l]) return fail(NBX_ERR_INVALID, "CSR offsets must be non-decreasing");
     if ((slots && !leaf_bodies) || (n_list && !list_sources)) return fail(NBX_ERR_INVALID, "null leaf arrays");
     {
-        std::vector<unsigned char> seen(n, 0);
+        std::vector<unsigned char> seen;
+        try { seen.assign(n, 0); } catch (...) { return fail(NBX_ERR_ALLOC, "host allocation failed"); }
         for (size_t s = 0; s < slots; ++s) {
             const uint32_t b = leaf_bodies[s];
             if (b >= n) return fail(NBX_ERR_INVALID, "leaf_bodies entry out of range");
@@ -732,6 +733,19 @@ int validate_csr(size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bo
     }
     *slots_out = slots;
     return NBX_OK;
+}
+
+// plan_leaves behind the C ABI: no exception leaves it (its arrays are std::vectors), an allocation failure is NBX_ERR_ALLOC
+int lay_out_launch(const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources,
+                   LeafPlan& plan) {
+    const char* why = nullptr;
+    try {
+        why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan, NBX_LEAF_PACK != 0);
+    } catch (...) {
+        why = kPlanAllocFailed;
+    }
+    if (!why) return NBX_OK;
+    return fail(why == kPlanAllocFailed ? NBX_ERR_ALLOC : NBX_ERR_INVALID, why);
 }
 
 // The caller's current HIP device is put back when an entry point of this file returns
@@ -792,7 +806,7 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
 
     // ---- the layout the kernel follows (leaf_plan.h; comment at the top of this file) ----
     static thread_local LeafPlan plan;   // a tree code calls once per step: the arrays keep their capacity (and their pages) between calls
-    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan, NBX_LEAF_PACK != 0)) return fail(NBX_ERR_INVALID, why);
+    if (int prc = lay_out_launch(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, plan)) return prc;
     const size_t pslots = plan.pslots();
     const std::vector<uint32_t>& pslot_body = plan.pslot_body;
     const std::vector<CopyOp>& ops = plan.ops;
@@ -956,7 +970,7 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     if (rc != NBX_OK) return rc;
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
     LeafPlan host;
-    if (const char* why = plan_leaves(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host, NBX_LEAF_PACK != 0)) return fail(NBX_ERR_INVALID, why);
+    if (int prc = lay_out_launch(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host)) return prc;
     nbx_leaf_plan* p = new (std::nothrow) nbx_leaf_plan();
     if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
     p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;

@@ -121,6 +121,7 @@ struct LeafPlan {
 //    order: eight runs of unequal durations side by side were measured 40 % SLOWER at 4-body leaves, the XCDs with the short
 //    blocks waiting for the dispatcher to get past the ones with the long blocks).
 constexpr uint32_t kXcds = 8;
+constexpr const char* kPlanAllocFailed = "host allocation failed while the launch was laid out";
 constexpr unsigned kPlanThreads = 8;            // host threads that lay out a launch's copy runs ...
 #ifndef NBX_PLAN_THREADS_FROM
 #define NBX_PLAN_THREADS_FROM 200000
@@ -134,9 +135,14 @@ constexpr size_t kXcdOrderFrom = NBX_XCD_ORDER_FROM;
 template <class F>
 inline void run_threads(unsigned n, F f) {
     std::thread helpers[kPlanThreads];
-    for (unsigned t = 1; t < n && t < kPlanThreads; ++t) helpers[t] = std::thread(f, t);
+    if (n > kPlanThreads) n = kPlanThreads;
+    unsigned started = 1;                               // pieces [1, started) run on threads of their own, the others here
+    for (; started < n; ++started) {
+        try { helpers[started] = std::thread(f, started); } catch (...) { break; }   // no thread to be had: that piece and the rest run here
+    }
     f(0u);
-    for (unsigned t = 1; t < n && t < kPlanThreads; ++t) helpers[t].join();
+    for (unsigned t = started; t < n; ++t) f(t);
+    for (unsigned t = 1; t < started; ++t) helpers[t].join();
 }
 
 template <class Block, class Dur>
@@ -224,6 +230,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     cut[n_threads] = n_leaves;
     const char* part_err[kPlanThreads] = {nullptr};
     auto lay_out = [&](unsigned t) {
+      try {                                               // nothing may leave a thread (or the C ABI above) as an exception
         std::vector<CopyOp> mine;                       // this thread's own header: the scratch arrays' headers sit side by side in
         mine.swap(plan.part_ops[t]);                    // one cache line, and push_back writes the header every time
         struct PutBack { std::vector<CopyOp>& a; std::vector<CopyOp>& b; ~PutBack() { a.swap(b); } } put_back{mine, plan.part_ops[t]};
@@ -250,6 +257,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             close_run();
             stream_units[l] = (uint32_t)stream;
         }
+      } catch (...) { part_err[t] = kPlanAllocFailed; }
     };
     run_threads(n_threads, lay_out);
     size_t base[kPlanThreads + 1];
