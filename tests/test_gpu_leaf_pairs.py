@@ -250,6 +250,25 @@ def test_packed_small_leaves(nbx, oracle, dim, box):
     _check(nbx, oracle, heavy, grid, nbx.LAW_FMM_P2P, f"packed grid leaves, guarded by a heavy mass, D={dim}, box {box:g}")
 
 
+@pytest.mark.parametrize("shape", ("packed grid cells", "median-split 16", "median-split 8"))
+def test_large_launches_xcd_order_and_threaded_layout(nbx, oracle, shape):
+    """Launches of more than 4,096 workgroups (csrc/leaf_plan.h order_launch deals the blocks of a duration class to the XCDs) and
+    lists of more than 200,000 entries (the layout's copy runs, padded slots and packed waves are built on 8 host threads): every
+    body of the structure against the oracle, all three ways in.  N = 2^18: 32^3 grid cells of ~8 bodies (packed, > 4,096 waves,
+    880,000 list entries), median-split leaves of 16 bodies (16,384 one-leaf workgroups) and of 8 bodies (32,768 leaves, packed)."""
+    n = 1 << 18
+    b = oracle.round_inputs_to_f32(oracle.generate(177, n, 3))
+    if shape == "packed grid cells":
+        leaves = nbx.leaves.uniform_grid_leaves(b, 3, 5)
+    else:
+        leaves = nbx.leaves.median_split_leaves(b, 3, 16 if shape.endswith("16") else 8, reach=0.5)
+    assert leaves[3].size > 200000
+    with nbx.LeafPlan(n, 3, *leaves) as plan:
+        slots, runs, groups, waves = plan.info()
+        assert groups > 4096, (shape, groups)
+    _check(nbx, oracle, b, leaves, nbx.LAW_TREE_LEAF, f"large launch, {shape}")
+
+
 def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
     b = oracle.generate(1, 10, 3)
     ok = (np.array([0, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1]))
