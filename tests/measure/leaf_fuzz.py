@@ -1,6 +1,6 @@
 """Measurement / robustness run (GPU box, not part of the suite): random leaf structures through nbx_leaf_pair_forces against the
 oracle -- leaf sizes from empty to several workgroups, lists with repeats, empty and consecutive leaves, streams of several tiles,
-bodies in no leaf, structures of tiny leaves (packed several to a wave), small and large coordinate boxes (guarded and unguarded waves, and both in one launch), masses above and below the
+bodies in no leaf, structures of tiny leaves (packed several to a wave), launches of tens of thousands of leaves, small and large coordinate boxes (guarded and unguarded waves, and both in one launch), masses above and below the
 bound of the unguarded loop, planted identical positions; both dimensions, all three laws.
     python tests/measure/leaf_fuzz.py [cases] [seed]"""
 import os
@@ -17,10 +17,12 @@ from oracle_lib import Oracle, assert_force_parity  # noqa: E402
 
 def one_case(rng, oracle, k):
     dim = int(rng.choice([2, 3]))
-    regime = rng.choice(["tiny", "small", "medium", "big", "mixed"])
+    regime = rng.choice(["tiny", "small", "medium", "big", "mixed", "many"], p=[0.19, 0.19, 0.19, 0.19, 0.19, 0.05])
     # tiny: a few bodies per leaf and many leaves -- the structures the planner PACKS, several leaves to a wave (mean leaf <= 8)
-    n_leaves = int(rng.integers(1, 300)) if regime == "tiny" else int(rng.integers(1, 40))
-    hi = {"tiny": int(rng.integers(2, 11)), "small": 20, "medium": 80, "big": 300, "mixed": 200}[regime]
+    # many: launches of more than 4,096 workgroups (dealt to the XCDs per duration class) whose lists have more than 200,000 entries
+    #       (laid out on 8 host threads), packed or not
+    n_leaves = int(rng.integers(1, 300)) if regime == "tiny" else int(rng.integers(9000, 30000)) if regime == "many" else int(rng.integers(1, 40))
+    hi = {"tiny": int(rng.integers(2, 11)), "small": 20, "medium": 80, "big": 300, "mixed": 200, "many": int(rng.choice([8, 12, 40]))}[regime]
     sizes = rng.integers(0, hi, n_leaves)
     if regime == "tiny" and rng.random() < 0.3:
         sizes[int(rng.integers(0, n_leaves))] = int(rng.integers(11, 40))   # one larger leaf among them (its own workgroup, or the 9-16 class)
@@ -46,7 +48,7 @@ def one_case(rng, oracle, k):
     lists = []
     for t in range(n_leaves):
         kind = rng.random()
-        length = int(rng.integers(0, 4)) if kind < 0.2 else int(rng.integers(1, 30)) if kind < 0.8 else int(rng.integers(60, 200))
+        length = int(rng.integers(0, 4)) if kind < 0.2 else int(rng.integers(1, 30)) if kind < 0.8 or regime == "many" else int(rng.integers(60, 200))
         l = rng.integers(0, n_leaves, length)
         if length >= 4 and rng.random() < 0.6:                          # a run of consecutive leaves (merged by the planner)
             s = int(rng.integers(0, n_leaves))
