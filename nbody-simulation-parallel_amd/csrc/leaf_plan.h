@@ -48,6 +48,10 @@ constexpr int kPackMaxOps = NBX_PACK_MAX_OPS;
 #define NBX_PACK_MEAN_LEAF 8   /* A/B builds raise it to pack larger leaves too */
 #endif
 constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
+#ifndef NBX_PACK_WINDOW_WAVES
+#define NBX_PACK_WINDOW_WAVES 8
+#endif
+constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leaves are picked from one window of neighbouring leaves (A/B builds: 32)
 constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -317,7 +321,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
         const size_t per_wave = k == 3 ? 4u : 8u;
         sub_base[k + 1] = sub_base[k] + packable[k].size();
         pack_base[k + 1] = pack_base[k] + (packable[k].size() + per_wave - 1u) / per_wave;
-        win_base[k + 1] = win_base[k] + (packable[k].size() + 8u * per_wave - 1u) / (8u * per_wave);
+        win_base[k + 1] = win_base[k] + (packable[k].size() + kPackWindowWaves * per_wave - 1u) / (kPackWindowWaves * per_wave);
     }
     subs.resize(sub_base[4]);
     packs.resize(pack_base[4]);
@@ -330,9 +334,9 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             const uint32_t w = k == 3 ? 16u : 8u, per_wave = 64u / w;
             const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : 2u;
             std::vector<uint32_t>& leaves_k = packable[k];
-            const size_t i = (wi - win_base[k]) * 8u * per_wave;
-            const size_t e = i + 8u * per_wave < leaves_k.size() ? i + 8u * per_wave : leaves_k.size();
-            uint64_t key[64];                           // longest first, leaf order among equals: one integer sort per window
+            const size_t i = (wi - win_base[k]) * kPackWindowWaves * per_wave;
+            const size_t e = i + kPackWindowWaves * per_wave < leaves_k.size() ? i + kPackWindowWaves * per_wave : leaves_k.size();
+            uint64_t key[kPackWindowWaves * 8u];                           // longest first, leaf order among equals: one integer sort per window
             for (size_t j = i; j < e; ++j) key[j - i] = ((uint64_t)(0xffffffffu - stream_units[leaves_k[j]]) << 32) | leaves_k[j];
             std::sort(key, key + (e - i));
             for (size_t j = i; j < e; ++j) leaves_k[j] = (uint32_t)key[j - i];
