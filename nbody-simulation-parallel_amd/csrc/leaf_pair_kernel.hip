@@ -373,7 +373,7 @@ struct LeafPackArgs {
     double* __restrict__ acc;
     const uint32_t* __restrict__ max_mass_bits;
 };
-constexpr int kPackMaxSubs = 8;                  // w >= 8
+constexpr int kPackMaxSubs = 16;                 // w >= 4
 
 #ifndef NBX_PACK_WAVES
 #define NBX_PACK_WAVES 4   /* waves per SIMD the register allocation aims at: 3D 110 VGPRs (5 spills 14 registers, 6 spills 34) */
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     const unsigned lane = threadIdx.x;
     const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
     const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, T = bp->trips;   // wave-uniform
-    const unsigned sub = lane >> wl, lw = lane & (w - 1u);         // w = 1 << wl is 8 or 16
+    const unsigned sub = lane >> wl, lw = lane & (w - 1u);         // w = 1 << wl is 4, 8 or 16
     PackSub my = PackSub{0u, 0u, 0u, 0u};
     if (sub < n_sub) my = a.subs[sub_lo + sub];
     // TWO targets per lane (t and t + W): a loaded source pair is used twice, and the loop's bookkeeping is shared by four terms

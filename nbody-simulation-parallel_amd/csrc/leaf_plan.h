@@ -52,6 +52,15 @@ constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
 #define NBX_PACK_WINDOW_WAVES 8
 #endif
 constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leaves are picked from one window of neighbouring leaves (A/B builds: 32)
+// lanes per leaf and lane groups per leaf of the four size classes (1-2, 3-4, 5-8, 9-16 bodies; a lane holds two targets)
+#ifndef NBX_PACK_TINY_LANES
+#define NBX_PACK_TINY_LANES 8   /* A/B: 4 = sixteen leaves of 1-4 bodies to a wave (measured: +10 % on median-split leaves of <= 4 bodies, -40 % on 64^3 grid cells) */
+#endif
+#ifndef NBX_PACK_SMALL_LANES
+#define NBX_PACK_SMALL_LANES NBX_PACK_TINY_LANES
+#endif
+constexpr uint32_t kPackLanes[4] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, 8u, 16u};
+constexpr uint32_t kPackGroups[4] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, 2u};
 constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -59,9 +68,9 @@ struct PackSub {                               // one packed leaf
 };
 struct PackBlock {                             // one wave64; read with scalar loads
     uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
-    uint32_t w, P;                             // lanes per leaf (8 | 16), lane groups per leaf (2 | 4 | 8): each walks 1 / P of the stream
+    uint32_t w, P;                             // lanes per leaf (8 | 16; 4 in A/B builds), lane groups per leaf (2 | 4 | 8): each walks 1 / P of the stream
     uint32_t trips;                            // source pairs every lane group walks: ceil(longest stream's pairs / P), rounded up to kPackPairsPerTrip
-    uint32_t w_log2;                           // 3 | 4
+    uint32_t w_log2;                           // 2 | 3 | 4
     uint32_t longest;                          // longest stream among the wave's leaves, in 16-byte units
     uint32_t pad_;
 };
@@ -298,8 +307,9 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     }
     // packed waves.  A lane holds two targets, so a leaf of c bodies takes ceil(c / 2) lanes per lane group.  Leaves are packed
     // with leaves of their own SIZE CLASS -- 1-2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2 lane groups), 9-16 bodies on 16 lanes
-    // (2 groups) -- in leaf order within the class, so that every wave runs the most lane groups its leaves allow (mixed, one
-    // 8-body leaf would hold seven smaller ones at two groups).
+    // (2 groups); kPackLanes / kPackGroups -- in leaf order within the class, so that every wave runs the most lane groups its
+    // leaves allow (mixed, one 8-body leaf would hold seven smaller ones at two groups).  Sixteen leaves of 1-4 bodies to a wave
+    // (4 lanes each) were measured too: profiles/r4/leaf_direct_ab.txt.
     std::vector<PackSub>& subs = plan.pack_subs;
     std::vector<PackBlock>& packs = plan.pack_blocks;
     subs.clear();
@@ -318,7 +328,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     // of 8 random ones is 12 % above the mean, of 8 consecutive ones of a sorted 64 2 %).
     size_t sub_base[5] = {0}, pack_base[5] = {0}, win_base[5] = {0};
     for (int k = 0; k < 4; ++k) {
-        const size_t per_wave = k == 3 ? 4u : 8u;
+        const size_t per_wave = 64u / kPackLanes[k];
         sub_base[k + 1] = sub_base[k] + packable[k].size();
         pack_base[k + 1] = pack_base[k] + (packable[k].size() + per_wave - 1u) / per_wave;
         win_base[k + 1] = win_base[k] + (packable[k].size() + kPackWindowWaves * per_wave - 1u) / (kPackWindowWaves * per_wave);
@@ -331,19 +341,19 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
         for (size_t wi = w_lo; wi < w_hi; ++wi) {
             int k = 0;
             while (wi >= win_base[k + 1]) ++k;
-            const uint32_t w = k == 3 ? 16u : 8u, per_wave = 64u / w;
-            const uint32_t P = k == 0 ? 8u : k == 1 ? 4u : 2u;
+            const uint32_t w = kPackLanes[k], per_wave = 64u / w;
+            const uint32_t P = kPackGroups[k];
             std::vector<uint32_t>& leaves_k = packable[k];
             const size_t i = (wi - win_base[k]) * kPackWindowWaves * per_wave;
             const size_t e = i + kPackWindowWaves * per_wave < leaves_k.size() ? i + kPackWindowWaves * per_wave : leaves_k.size();
-            uint64_t key[kPackWindowWaves * 8u];                           // longest first, leaf order among equals: one integer sort per window
+            uint64_t key[kPackWindowWaves * 16u];                          // longest first, leaf order among equals: one integer sort per window
             for (size_t j = i; j < e; ++j) key[j - i] = ((uint64_t)(0xffffffffu - stream_units[leaves_k[j]]) << 32) | leaves_k[j];
             std::sort(key, key + (e - i));
             for (size_t j = i; j < e; ++j) leaves_k[j] = (uint32_t)key[j - i];
             for (size_t i0 = i; i0 < e; i0 += per_wave) {
                 PackBlock b{};
                 b.sub_lo = (uint32_t)(sub_base[k] + i0);
-                b.w = w; b.w_log2 = k == 3 ? 4u : 3u; b.P = P;
+                b.w = w; b.w_log2 = w == 4u ? 2u : w == 8u ? 3u : 4u; b.P = P;
                 uint32_t longest = 0;
                 for (size_t j = i0; j < e && j < i0 + per_wave; ++j) {
                     const uint32_t l = leaves_k[j];

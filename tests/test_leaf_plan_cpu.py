@@ -124,7 +124,7 @@ def _check(plan, lo, lb, so, ss):
     n_ops_of = np.diff(op_off.astype(np.int64))
     seen_sub = np.zeros(subs.shape[0], dtype=np.int64)
     for sub_lo, n_sub, w, P, trips, _, longest, _ in packs:
-        assert w in (8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
+        assert w in (4, 8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
         assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 32).all()
@@ -132,7 +132,7 @@ def _check(plan, lo, lb, so, ss):
         # (8, 4, 2 lane groups), 9-16 bodies on 16 lanes (2 groups)
         cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 8 else 3
         k = cls(mine[0, 3])
-        assert all(cls(c) == k for c in mine[:, 3]) and w == (16 if k == 3 else 8) and P == (8, 4, 2, 2)[k]
+        assert all(cls(c) == k for c in mine[:, 3]) and w == (8, 8, 8, 16)[k] and P == (8, 4, 2, 2)[k]
         assert (-(-mine[:, 3] // 2) * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
         streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
         # every lane group walks the same number of source pairs: its share of the longest stream, an even number (the loop takes two at a time)
