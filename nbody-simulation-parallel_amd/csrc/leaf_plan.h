@@ -54,7 +54,7 @@ constexpr int kPackMeanLeaf = NBX_PACK_MEAN_LEAF;
 constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leaves are picked from one window of neighbouring leaves (A/B builds: 32)
 // lanes per leaf and lane groups per leaf of the four size classes (1-2, 3-4, 5-8, 9-16 bodies; a lane holds two targets)
 #ifndef NBX_PACK_TINY_LANES
-#define NBX_PACK_TINY_LANES 8   /* A/B: 4 = sixteen leaves of 1-4 bodies to a wave (measured: +10 % on median-split leaves of <= 4 bodies, -40 % on 64^3 grid cells) */
+#define NBX_PACK_TINY_LANES 4   /* A/B: 8 = eight leaves of 1-4 bodies to a wave, at 8 and 4 lane groups (this round's earlier layout) */
 #endif
 #ifndef NBX_PACK_SMALL_LANES
 #define NBX_PACK_SMALL_LANES NBX_PACK_TINY_LANES
@@ -68,7 +68,7 @@ struct PackSub {                               // one packed leaf
 };
 struct PackBlock {                             // one wave64; read with scalar loads
     uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
-    uint32_t w, P;                             // lanes per leaf (8 | 16; 4 in A/B builds), lane groups per leaf (2 | 4 | 8): each walks 1 / P of the stream
+    uint32_t w, P;                             // lanes per leaf (4 | 8 | 16), lane groups per leaf (2 | 4; 8 in A/B builds): each walks 1 / P of the stream
     uint32_t trips;                            // source pairs every lane group walks: ceil(longest stream's pairs / P), rounded up to kPackPairsPerTrip
     uint32_t w_log2;                           // 2 | 3 | 4
     uint32_t longest;                          // longest stream among the wave's leaves, in 16-byte units
@@ -306,10 +306,10 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
                             unit_off[n_leaves] < (1u << 28) - 2u;   // the packed kernel addresses units by 32-bit byte offsets
     }
     // packed waves.  A lane holds two targets, so a leaf of c bodies takes ceil(c / 2) lanes per lane group.  Leaves are packed
-    // with leaves of their own SIZE CLASS -- 1-2, 3-4, 5-8 bodies on 8 lanes each (8, 4, 2 lane groups), 9-16 bodies on 16 lanes
-    // (2 groups); kPackLanes / kPackGroups -- in leaf order within the class, so that every wave runs the most lane groups its
-    // leaves allow (mixed, one 8-body leaf would hold seven smaller ones at two groups).  Sixteen leaves of 1-4 bodies to a wave
-    // (4 lanes each) were measured too: profiles/r4/leaf_direct_ab.txt.
+    // with leaves of their own SIZE CLASS -- 1-2 and 3-4 bodies on 4 lanes each (4 and 2 lane groups: 16 leaves to a wave, so that
+    // a wave's start-up and closing reduction, ~400 instructions, are shared by 16 leaves and its loop is twice as long), 5-8
+    // bodies on 8 lanes, 9-16 bodies on 16 lanes (2 groups each); kPackLanes / kPackGroups -- in leaf order within the class, so
+    // that every wave runs the most lane groups its leaves allow (mixed, one 8-body leaf would hold seven smaller ones at two groups).
     std::vector<PackSub>& subs = plan.pack_subs;
     std::vector<PackBlock>& packs = plan.pack_blocks;
     subs.clear();
@@ -395,7 +395,9 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
         }
     }
     section(2);
-    order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips; });
+    // waves of different shapes (lanes per leaf, lane groups) never share a duration class: equal trips are not equal durations, and
+    // the blocks of a class are dealt to the XCDs side by side
+    order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips * 8u + (b.w_log2 - 2u) * 2u + (b.P > 2u ? 1u : 0u); });
     order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
     section(3);
 

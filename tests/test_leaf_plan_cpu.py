@@ -128,11 +128,11 @@ def _check(plan, lo, lb, so, ss):
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
         assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 32).all()
-        # leaves share a wave with leaves of their size class (a lane holds two targets): 1-2, 3-4, 5-8 bodies on 8 lanes
-        # (8, 4, 2 lane groups), 9-16 bodies on 16 lanes (2 groups)
+        # leaves share a wave with leaves of their size class (a lane holds two targets): 1-2 and 3-4 bodies on 4 lanes (4 and 2 lane
+        # groups), 5-8 bodies on 8 lanes, 9-16 bodies on 16 lanes (2 groups each)
         cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 8 else 3
         k = cls(mine[0, 3])
-        assert all(cls(c) == k for c in mine[:, 3]) and w == (8, 8, 8, 16)[k] and P == (8, 4, 2, 2)[k]
+        assert all(cls(c) == k for c in mine[:, 3]) and w == (4, 4, 8, 16)[k] and P == (4, 2, 2, 2)[k]
         assert (-(-mine[:, 3] // 2) * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
         streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
         # every lane group walks the same number of source pairs: its share of the longest stream, an even number (the loop takes two at a time)
@@ -232,11 +232,11 @@ def test_workgroups_of_a_class_are_dealt_to_the_xcds_in_runs(planner_xcd, tmp_pa
     tiny = [4] * 6000
     d = tmp_path / "tiny"
     d.mkdir()
-    lo, lb, so, ss = _structure(12, tiny, lambda t: [3, 9, 12][(t // 8) % 3])       # eight leaves to a wave: waves of three durations
+    lo, lb, so, ss = _structure(12, tiny, lambda t: [3, 9, 12][(t // 16) % 3])      # sixteen 4-body leaves to a wave: waves of three durations
     plan = planner_xcd(str(d), lo, lb, so, ss)
     _check(plan, lo, lb, so, ss)
     packs, subs = plan["pack_blocks"].astype(np.int64), plan["pack_subs"].astype(np.int64)
-    assert packs.shape[0] >= 500
+    assert packs.shape[0] >= 300
     # packed waves of one duration class can belong to different size classes (built class by class, each in leaf order): the runs are
     # consecutive in BUILD order, which is the order of their first sub-leaf
     assert _check_xcd_runs(packs[:, 4], packs[:, 0]) >= 2
