@@ -397,7 +397,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     section(2);
     // waves of different shapes (lanes per leaf, lane groups) never share a duration class: equal trips are not equal durations, and
     // the blocks of a class are dealt to the XCDs side by side
-    order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips * 8u + (b.w_log2 - 2u) * 2u + (b.P > 2u ? 1u : 0u); });
+    order_launch(packs, [](const PackBlock& b) -> uint32_t { return (b.trips < (1u << 28) ? b.trips : (1u << 28)) * 8u + (b.w_log2 - 2u) * 2u + (b.P > 2u ? 1u : 0u); });
     order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
     section(3);
 
