@@ -297,12 +297,13 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
         const uint32_t u_end = a.ops[op_lo + c0 + n_ops - 1u].end;
         __syncthreads();
         unsigned k = 0;                                        // this lane's cursor in the chunk's ops; only ever moves forward
+        uint32_t run_end = 0u, run_base = 0u;                  // the run it is in, in registers (every unit read them from LDS before: two reads and their waits)
         // kUnitsPerLane named registers (an indexed array ends up in scratch)
         float4 nxt0 = pad_unit, nxt1 = pad_unit, nxt2 = pad_unit, nxt3 = pad_unit;
         auto load1 = [&](const uint32_t u, float4& v) {
             if (u < u_end) {
-                while (u >= op_end[k]) ++k;
-                v = a.xp[op_base[k] + u];
+                while (u >= run_end) { run_end = op_end[k]; run_base = op_base[k]; ++k; }   // u < u_end = the last run's end: k stays inside the chunk
+                v = a.xp[run_base + u];
             }
         };
         auto load = [&](const uint32_t u0) {
