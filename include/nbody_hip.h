@@ -174,6 +174,11 @@ int nbx_leaf_plan_get_forces(nbx_leaf_plan* plan, double* forces_out);
  * Asynchronous on the context's stream.  This is the stepping loop of a tree code whose far field is zero: what `nbody_sim
  * -m p --steps k` runs. */
 int nbx_leaf_plan_kick_drift(nbx_leaf_plan* plan, nbx_ctx* ctx, double dt);
+/* nsteps x { nbx_leaf_plan_forces_ctx(plan, ctx, law, G, NULL, NULL); nbx_leaf_plan_kick_drift(plan, ctx, dt) } with the structure
+ * standing (the loop of methods.cpp:425-450 around the leaf sums; same kernels, same arithmetic, same results), in one call:
+ * the steps are queued ahead of the device without the two calls' event bookkeeping.  Asynchronous; afterwards the plan holds the
+ * LAST step's sums (of the positions before that step's drift), as after the two calls.  nsteps >= 0. */
+int nbx_leaf_plan_step(nbx_leaf_plan* plan, nbx_ctx* ctx, int law, double G, double dt, int nsteps);
 /* MEASUREMENT entry (tools/, bench.py): the pair kernel launched `reps` times back to back on the bodies of the last
  * evaluation (same sums every time); mean_ms = mean duration of the second half of the launches -- the kernel with the clocks
  * up, which a single launch from idle does not see.  1 <= reps <= 1000.  Synchronises. */

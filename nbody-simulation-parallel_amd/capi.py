@@ -47,6 +47,7 @@ ABI = [
     ("nbx_leaf_plan_forces_ctx", _i, [_vp, _vp, _i, _d, _vp, _pf]),
     ("nbx_leaf_plan_get_forces", _i, [_vp, _vp]),
     ("nbx_leaf_plan_kick_drift", _i, [_vp, _vp, _d]),
+    ("nbx_leaf_plan_step", _i, [_vp, _vp, _i, _d, _d, _i]),
     ("nbx_leaf_plan_time_kernel", _i, [_vp, _i, _i, _pf]),
     ("nbx_leaf_plan_info", _i, [_vp, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz), _pi]),
     ("nbx_ctx_create", _i, [_c.POINTER(_vp), _i, _i, _sz, _i, _i]),
@@ -321,6 +322,10 @@ class LeafPlan:
 
     def kick_drift(self, ctx: "Context", dt: float):
         self._ck(self.lib.nbx_leaf_plan_kick_drift(self.h, ctx.h, float(dt)), "nbx_leaf_plan_kick_drift")
+
+    def step(self, ctx: "Context", law: int, G: float, dt: float, nsteps: int):
+        """nsteps x {forces_ctx(fetch=False); kick_drift} in one call (nbx_leaf_plan_step)."""
+        self._ck(self.lib.nbx_leaf_plan_step(self.h, ctx.h, int(law), float(G), float(dt), int(nsteps)), "nbx_leaf_plan_step")
 
     def time_kernel(self, law: int, reps: int) -> float:
         """Measurement: mean ms of the second half of `reps` back-to-back launches of the pair kernel."""

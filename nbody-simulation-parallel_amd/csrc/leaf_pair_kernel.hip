@@ -499,6 +499,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     }
 }
 
+// The call's largest |mass| (as fp32 bits) into one word: the block's maximum through LDS, then ONE lane per block, and only when an
+// ordinary (cached) read of the word says the block's maximum is above it.  16,384 atomics on the word cost 0.15 ms; so did 16,384
+// atomic LOADS of it (one L2 channel serves them one after the other) -- the resident gather spent 0.12 of its 0.14 ms there.  A stale
+// read only costs a superfluous atomicMax; the atomic decides.
+__device__ __forceinline__ void publish_max_mass(uint32_t wave_max, uint32_t* __restrict__ max_mass_bits) {
+    __shared__ uint32_t block_max[4];
+    if ((threadIdx.x & 63u) == 0u) block_max[threadIdx.x >> 6] = wave_max;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t m = block_max[0];
+        for (unsigned w = 1; w < (blockDim.x + 63u) / 64u; ++w) m = block_max[w] > m ? block_max[w] : m;
+        if (m > *static_cast<volatile const uint32_t*>(max_mass_bits)) atomicMax(max_mass_bits, m);
+    }
+}
+
 // the launch's pad pair, behind the last leaf's slots (pslots is even: every leaf is padded to whole pairs); the arrays' arena keeps
 // 256 bytes of slack behind each of them
 __device__ __forceinline__ void write_pad_pair(float* __restrict__ xp, uint32_t pslots, int dim) {
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const double* __restri
         mb = other > mb ? other : mb;
     }
     // one lane per wave, and only while the wave's maximum is above what is already there (16,384 atomics on one word cost 0.15 ms)
-    if ((threadIdx.x & 63u) == 0u && mb > __atomic_load_n(max_mass_bits, __ATOMIC_RELAXED)) atomicMax(max_mass_bits, mb);
+    publish_max_mass(mb, max_mass_bits);
     if (p == 0u) write_pad_pair(xp, pslots, dim);
     if (p >= pslots) return;
     float* __restrict__ o = xp + (size_t)(p >> 1) * 8u + (p & 1u);
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(256) void leaf_gather_by_body_kernel(const float* _
         const uint32_t other = (uint32_t)__shfl_xor((int)mb, d);
         mb = other > mb ? other : mb;
     }
-    if ((threadIdx.x & 63u) == 0u && mb > __atomic_load_n(max_mass_bits, __ATOMIC_RELAXED)) atomicMax(max_mass_bits, mb);
+    publish_max_mass(mb, max_mass_bits);
     if (slot == 0xffffffffu) return;
     float* __restrict__ o = xp + (size_t)(slot >> 1) * 8u + (slot & 1u);
     o[0] = x; o[2] = y; o[4] = z; o[6] = m;
@@ -1092,6 +1107,19 @@ int nbx_leaf_plan_forces(nbx_leaf_plan* p, const void* bodies, size_t stride_byt
     return NBX_OK;
 }
 
+// positions and masses of a context's resident bodies -> the plan's leaf-ordered source pairs, on stream s.  One lane per body
+// (coalesced reads, four 4-byte stores into its slot's pair record): 0.048 ms at N = 2^20.  A two-kernel form (SoA -> one float4 per
+// body, then one lane per slot reading its body's 16 bytes and writing whole records) was measured at 0.006 + 0.044 ms: no better.
+// What had made this gather 0.14-0.17 ms was not its memory traffic but publish_max_mass's predecessor (tools/ubench_gather.hip:
+// the traffic alone is 0.02 ms back to back).
+static int plan_gather_resident(nbx_leaf_plan* p, nbx_ctx* c, hipStream_t s) {
+    if (!p->pslots || !p->n) return NBX_OK;
+    hipLaunchKernelGGL(leaf_gather_by_body_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, s, c->pos_all, c->mass_all, c->pad, p->dim,
+                       p->body_slot, p->n, reinterpret_cast<float*>(p->xp), p->max_mass);
+    NBX_HIP_TRY(hipGetLastError());
+    return NBX_OK;
+}
+
 int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, double* forces_out, float* kernel_ms) {
     if (kernel_ms) *kernel_ms = 0.0f;
     if (!p || !c) return fail(NBX_ERR_INVALID, "null argument");
@@ -1105,11 +1133,7 @@ int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, do
     hipStream_t s = c->stream;
     if ((rc = plan_order_after_last(p, s))) return rc;
     NBX_HIP_TRY(hipMemsetAsync(p->max_mass, 0, sizeof(uint32_t), s));
-    if (p->pslots && p->n) {   // body-major: coalesced reads, one 32-byte sector written per body; the pads were written at creation
-        hipLaunchKernelGGL(leaf_gather_by_body_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, s, c->pos_all, c->mass_all, c->pad, p->dim,
-                           p->body_slot, p->n, reinterpret_cast<float*>(p->xp), p->max_mass);
-        NBX_HIP_TRY(hipGetLastError());
-    }
+    if ((rc = plan_gather_resident(p, c, s))) return rc;
     if ((rc = plan_launch_pairs(p, law, s, kernel_ms != nullptr))) return rc;
     p->evaluated = true; p->last_law = law;
     p->last_signedG = (law == NBX_LAW_BRUTE) ? -G : G;
@@ -1148,6 +1172,45 @@ int nbx_leaf_plan_kick_drift(nbx_leaf_plan* p, nbx_ctx* c, double dt) {
     k.sums = p->sums; k.body_slot = p->body_slot; k.pslots = (uint32_t)p->pslots; k.dim = p->dim; k.pad = c->pad; k.count = c->count;
     k.signedG = p->last_signedG; k.dt = dt; k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64; k.pos_chunk = c->pos_all;
     NBX_HIP_TRY(launch_kick_drift_slots(k, s));
+    c->have_accel = false;                          // the context's own accelerations (if any) belong to the old positions
+    c->tgt_cand_valid = 0; c->bad_list_pass = -1;
+    return plan_mark_done(p, s);
+}
+
+// one step's device work on stream s, nothing else (no events, no waits)
+static int plan_enqueue_step(nbx_leaf_plan* p, nbx_ctx* c, int law, double signedG, double dt, hipStream_t s) {
+    NBX_HIP_TRY(hipMemsetAsync(p->max_mass, 0, sizeof(uint32_t), s));
+    if (int rc = plan_gather_resident(p, c, s)) return rc;
+    if (int rc = plan_launch_pairs(p, law, s, false)) return rc;
+    SlotKickArgs k;
+    k.sums = p->sums; k.body_slot = p->body_slot; k.pslots = (uint32_t)p->pslots; k.dim = p->dim; k.pad = c->pad; k.count = c->count;
+    k.signedG = signedG; k.dt = dt; k.x64 = c->x64; k.v64 = c->v64; k.m64 = c->m64; k.pos_chunk = c->pos_all;
+    NBX_HIP_TRY(launch_kick_drift_slots(k, s));
+    return NBX_OK;
+}
+
+int nbx_leaf_plan_step(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, double dt, int nsteps) {
+    if (!p || !c) return fail(NBX_ERR_INVALID, "null argument");
+    if (law < NBX_LAW_BRUTE || law > NBX_LAW_FMM_P2P) return fail(NBX_ERR_INVALID, "unknown law");
+    if (nsteps < 0) return fail(NBX_ERR_INVALID, "nsteps must be >= 0");
+    if (c->device != p->device || c->dim != p->dim || c->n_total != p->n || c->n_shards != 1)
+        return fail(NBX_ERR_INVALID, "the context must be a single-shard context of the plan's device, dimension and body count");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies to the context first");
+    if (nsteps == 0) return NBX_OK;
+    DeviceScope scope;
+    int rc = plan_set_device(p);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = plan_order_after_last(p, s))) return rc;
+    const double signedG = (law == NBX_LAW_BRUTE) ? -G : G;
+    // Plain launches, queued ahead of the device: a step is GPU-bound (0.36 ms of kernels at N = 2^20; 5 launches cost the host
+    // ~25 us).  A captured HIP graph was measured: 8-15 ms to capture and instantiate, then the same 72.4 ms per 200 steps at
+    // N = 2^20 and 7.97 against 8.39 ms at N = 20,000 -- it would need thousands of steps to pay for itself (tools/time_leaf_steps.py).
+    for (int k = 0; k < nsteps; ++k)
+        if ((rc = plan_enqueue_step(p, c, law, signedG, dt, s))) return rc;
+    p->evaluated = true; p->last_law = law;
+    p->last_signedG = signedG;
+    p->last_mass = c->m64; p->last_mass_stride = 1;
     c->have_accel = false;                          // the context's own accelerations (if any) belong to the old positions
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     return plan_mark_done(p, s);

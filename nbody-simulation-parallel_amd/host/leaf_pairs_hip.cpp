@@ -86,11 +86,8 @@ void LeafPairSimulationHip<D>::evaluate(LeafLaw law, double G) {
 }
 template <int D>
 void LeafPairSimulationHip<D>::step(LeafLaw law, double G, double dt, int nsteps) {
-    for (int s = 0; s < nsteps; ++s) {
-        int rc = nbx_leaf_plan_forces_ctx(plan_, ctx_, static_cast<int>(law), G, nullptr, nullptr);
-        if (!rc) rc = nbx_leaf_plan_kick_drift(plan_, ctx_, dt);
-        if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::step", rc);
-    }
+    const int rc = nbx_leaf_plan_step(plan_, ctx_, static_cast<int>(law), G, dt, nsteps);
+    if (rc != NBX_OK) raise_leaf("LeafPairSimulationHip::step", rc);
 }
 template <int D>
 void LeafPairSimulationHip<D>::synchronize() {

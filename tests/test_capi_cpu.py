@@ -182,7 +182,7 @@ def test_new_entry_points_validate_and_fail_loudly_without_a_device(nbx):
         assert e.value.status == 2
     z = ctypes.c_float(0.0)
     for fn, args in ((lib.nbx_leaf_plan_forces, (None, None, 56, 1, 1.0, None, None)), (lib.nbx_leaf_plan_forces_ctx, (None, None, 1, 1.0, None, None)),
-                     (lib.nbx_leaf_plan_get_forces, (None, None)), (lib.nbx_leaf_plan_kick_drift, (None, None, 1.0)),
+                     (lib.nbx_leaf_plan_get_forces, (None, None)), (lib.nbx_leaf_plan_kick_drift, (None, None, 1.0)), (lib.nbx_leaf_plan_step, (None, None, 1, 1.0, 1.0, 1)),
                      (lib.nbx_leaf_plan_time_kernel, (None, 1, 3, ctypes.byref(z))), (lib.nbx_leaf_plan_info, (None, None, None, None, None)),
                      (lib.nbx_ctx_upload_shard, (None, None, 56, None, None)), (lib.nbx_ctx_upload_finish, (None, 1.0, 1.0)),
                      (lib.nbx_ctx_refine_time, (None, ctypes.byref(z))), (lib.nbx_node_refine_stats, (None, None, None)),

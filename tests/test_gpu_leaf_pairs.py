@@ -381,6 +381,46 @@ def test_plan_stepping_matches_the_reference_helpers(nbx, oracle):
     assert_force_parity(fb, oracle.brute_force_seq(cur) * scale, oracle.force_magnitude_sums(cur) * scale, "brute force after the plan's drifts")
 
 
+@pytest.mark.parametrize("shape", ("grid cells of ~40 bodies", "packed grid cells"))
+def test_plan_step_equals_the_two_calls(nbx, oracle, shape):
+    """nbx_leaf_plan_step(plan, ctx, law, G, dt, k) leaves the bodies and the plan's sums exactly as k x {nbx_leaf_plan_forces_ctx;
+    nbx_leaf_plan_kick_drift} do: bit for bit, call after call, after dt changed, with another context, and for k = 0."""
+    n, dim, G = 20000, 3, oracle.G * 1e26
+    b0 = oracle.round_inputs_to_f32(oracle.generate(151, n, dim))
+    leaves = nbx.leaves.uniform_grid_leaves(b0, dim, 3 if shape.startswith("grid") else 4)
+    law = nbx.LAW_TREE_LEAF
+
+    def by_calls(c, plan, dt, k):
+        for _ in range(k):
+            plan.forces_ctx(c, law, G, fetch=False)
+            plan.kick_drift(c, dt)
+
+    with nbx.LeafPlan(n, dim, *leaves) as pa, nbx.LeafPlan(n, dim, *leaves) as pb, nbx.Context(n, dim) as ca, nbx.Context(n, dim) as cb, nbx.Context(n, dim) as cc:
+        for c in (ca, cb, cc):
+            c.upload(b0)
+        ga, gb = b0.copy(), b0.copy()
+        for dt, k in ((1.5, 3), (1.5, 2), (0.75, 2), (0.75, 0), (0.75, 1)):
+            by_calls(ca, pa, dt, k)
+            pb.step(cb, law, G, dt, k)
+            ca.download(ga); cb.download(gb)
+            assert np.array_equal(ga, gb), f"bodies after {k} steps of dt = {dt}"
+            if k:
+                assert np.array_equal(pa.get_forces(), pb.get_forces()), "the plan's sums after the last step"
+        assert not np.array_equal(ga[:, dim:2 * dim], b0[:, dim:2 * dim]), "coupling too weak to test anything"
+        pb.step(cc, law, G, 1.5, 3)                     # another context: its arrays, not the first one's
+        by_calls(ca, pa, 1.5, 0)
+        gc = b0.copy()
+        cc.download(gc)
+        with nbx.Context(n, dim) as cd:
+            cd.upload(b0)
+            by_calls(cd, pa, 1.5, 3)
+            gd = b0.copy()
+            cd.download(gd)
+        assert np.array_equal(gc, gd)
+        cb.download(gb)
+        assert np.array_equal(ga, gb), "stepping another context must leave the first one alone"
+
+
 def test_calls_reuse_the_parked_device_allocation(nbx, oracle):
     """A finished call parks its device allocation for the next one on that device (a tree code calls once per step); results must
     not depend on what the allocation held before: a large call, then smaller ones of another shape, a release in between."""
