@@ -550,12 +550,15 @@ def main():
                 result["tolerance_met_for_all_bodies"] = bool(ab[ab["headline_mode"]]["n_over_1e-5"] == 0)
             if world > 1:
                 result["accuracy"]["nccl_parity_path"] = "first contact: this N > 1 parity path had only been rehearsed over gloo on one GPU before this run"
-            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)   # rank 0's host cores, after the last collective
-            if world == 1 and args.dim == 3:
+            other = None
+            if world == 1 and args.dim == 3:   # before the CPU baseline: 20 s of host-only work send the GPU's clocks down, and a 0.3-ms kernel does not bring them back
                 try:
-                    result["other_kernels"] = {"leaf_pair": leaf_pair_roofline(local_rank)}
+                    other = {"leaf_pair": leaf_pair_roofline(local_rank)}
                 except Exception as e:   # never at the expense of the headline line
-                    result["other_kernels"] = {"leaf_pair": f"not measured: {e.__class__.__name__}: {e}"}
+                    other = {"leaf_pair": f"not measured: {e.__class__.__name__}: {e}"}
+            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)   # rank 0's host cores, after the last collective
+            if other is not None:
+                result["other_kernels"] = other
         print(json.dumps(result), flush=True)
     be.close()
     if world > 1:
