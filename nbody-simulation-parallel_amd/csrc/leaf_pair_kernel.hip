@@ -20,7 +20,7 @@
 //    tile's pairs between them; the host cuts the leaf where the two pieces together waste the fewest lanes
 //    (43 targets: 11 x 5 lanes + 32 x 2 lanes = 96 % of the lanes busy; one wave64 with one lane each: 67 %).  Small leaves
 //    (a mean of <= 20 bodies) get one wave per workgroup and no cut;
-//  * structures of SMALL leaves (a mean of <= 8 bodies) are PACKED instead: 4 or 8 leaves share a wave64, every lane holds two
+//  * structures of SMALL leaves (a mean of <= 8 bodies) are PACKED instead: 4, 8 or 16 leaves share a wave64, every lane holds two
 //    targets and streams its share of its leaf's source pairs straight from memory (leaf_pack_kernel below; leaf_plan.h);
 //  * the workgroups are launched longest first, so that the launch drains in a fraction of a mean workgroup's time, and the
 //    blocks of a duration class are dealt to the eight XCDs in consecutive runs (leaf_plan.h order_launch);

@@ -29,7 +29,7 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // ---- packed small leaves (round 4) ----
 // A leaf of a few bodies cannot fill a wave: at 4 bodies per leaf a workgroup's start-up, staging and closing reduction cost ten
 // times its pair arithmetic (0.06 of the fp32 peak in round 3).  Leaves of up to kPackMaxTargets bodies whose list is at most
-// kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 8 or 16 lanes --
+// kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 4, 8 or 16 lanes --
 // its own copy runs, P lane groups (two targets per lane; the same P for every leaf of the wave -- leaves are packed with leaves of their size class
 // -- so that every lane runs the same trip count), each lane group streaming its share of its leaf's source pairs straight from
 // memory -- and all of them run the pair loop together.  Everything else (larger leaves, longer lists) keeps the one-leaf
