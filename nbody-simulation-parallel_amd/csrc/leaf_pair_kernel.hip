@@ -165,6 +165,13 @@ struct Sums {
         ay = __builtin_elementwise_fma(w, q.dy, ay);
         if (D == 3) az = __builtin_elementwise_fma(w, q.dz, az);
     }
+    __device__ __forceinline__ void store() {   // flush() into sums that hold nothing yet: no read, no zeroing beforehand
+        o[0] = (double)ax.x + (double)ax.y;
+        o[stride] = (double)ay.x + (double)ay.y;
+        if (D == 3) o[2u * stride] = (double)az.x + (double)az.y;
+        ax = ay = az = f2{0.f, 0.f};
+        pending = 0;
+    }
     __device__ __forceinline__ void flush() {
         o[0] += (double)ax.x + (double)ax.y;
         o[stride] += (double)ay.x + (double)ay.y;
@@ -398,8 +405,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     const bool valid1 = valid && t + W < my.count;                 // a leaf of odd size: its last lane holds one target
     const unsigned g = valid ? g_raw : 0u;
     const uint32_t pslot0 = my.first + (valid ? t : 0u), pslot1 = valid1 ? pslot0 + W : pslot0;
-    const float* __restrict__ xf0 = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot0 >> 1) * 8u + (pslot0 & 1u);
-    const float* __restrict__ xf1 = reinterpret_cast<const float*>(a.xp) + (size_t)(pslot1 >> 1) * 8u + (pslot1 & 1u);
+    const char* __restrict__ const xp_bytes = reinterpret_cast<const char*>(a.xp);   // 32-bit byte offsets from a scalar base: the plan packs nothing beyond 2^28 units
+    const float* __restrict__ xf0 = reinterpret_cast<const float*>(xp_bytes + ((pslot0 >> 1) * 32u + (pslot0 & 1u) * 4u));
+    const float* __restrict__ xf1 = reinterpret_cast<const float*>(xp_bytes + ((pslot1 >> 1) * 32u + (pslot1 & 1u) * 4u));
     float ix = 0.f, iy = 0.f, iz = 0.f, jx = 0.f, jy = 0.f, jz = 0.f;
     if (my.count) { ix = xf0[0]; iy = xf0[2]; jx = xf1[0]; jy = xf1[2]; if (D == 3) { iz = xf0[4]; jz = xf1[4]; } }
     const f2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz}, jx2 = {jx, jx}, jy2 = {jy, jy}, jz2 = {jz, jz};
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     }
     if (lw == 0u) { op_end[sub][my.op_n] = 0xffffffffu; op_base[sub][my.op_n] = a.pslots << 4; }
     Sums<D> S0, S1;
-    for (int c = 0; c < 3; ++c) { osum[c][lane] = 0.0; osum[c][64u + lane] = 0.0; }
+    bool flushed = false;                                          // wave-uniform: the fp64 sums hold something (they are not zeroed: the first flush stores)
     S0.o = &osum[0][lane];
     S1.o = &osum[0][64u + lane];
     S0.stride = S1.stride = 128u;
@@ -436,7 +444,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         }
         return ((v & run_mask) << 4) + run_off;                    // a run is whole leaves, a leaf whole pairs: both units of the pair
     };
-    const char* __restrict__ const xp_bytes = reinterpret_cast<const char*>(a.xp);
     auto issue = [&](const uint32_t i, float4 (&A)[2], float4 (&B)[2]) {   // pairs i and i + 1 of this lane's share
         const uint32_t v = v_begin + 2u * i;
         const uint32_t o0 = offset_of(v), o1 = offset_of(v + 2u);
@@ -458,7 +465,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
             S.add(q, wgt);
         };
         auto compute = [&](const float4 (&A)[2], const float4 (&B)[2]) {
-            if (S0.pending + 4u > kFlushTerms) { S0.flush(); S1.flush(); }
+            if (S0.pending + 4u > kFlushTerms) {
+                if (flushed) { S0.flush(); S1.flush(); } else { S0.store(); S1.store(); flushed = true; }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 term(A[j], B[j], ix2, iy2, iz2, S0);
@@ -483,8 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         if (safe) run(std::false_type{});
         else run(std::true_type{});
     }
-    S0.flush();
-    S1.flush();
+    if (flushed) { S0.flush(); S1.flush(); } else { S0.store(); S1.store(); }   // T = 0: zeros are stored
     __syncthreads();
     if (valid && g == 0u) {
         const unsigned l0 = sub * w + t;
