@@ -256,3 +256,28 @@ def test_the_layout_does_not_depend_on_the_number_of_threads(planner, planner_th
         _check(many, lo, lb, so, ss)
         for k in one:
             assert np.array_equal(one[k], many[k]), k
+
+
+def test_the_threaded_layout_is_race_free(tmp_path):
+    """The same driver under ThreadSanitizer with the threads (and the XCD order) switched on from small sizes: a launch of one-leaf
+    workgroups and a launch of packed waves, no report.  (Skipped where the sanitizer's runtime cannot start.)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import nbody_amd as nbx
+    exe = str(tmp_path / "leaf_plan_tsan")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-DNBX_PLAN_THREADS_FROM=64", "-DNBX_XCD_ORDER_FROM=16", "-pthread",
+                            os.path.join(ROOT, "tests", "leaf_plan_check.cpp"), "-o", exe], capture_output=True, text=True)
+    if build.returncode:
+        pytest.skip("no ThreadSanitizer build here: " + build.stderr[-200:])
+    cases = {"grid": (nbx.uniform_bodies(60000, 3, 3), lambda b: nbx.leaves.uniform_grid_leaves(b, 3, 4)),
+             "bvh": (nbx.uniform_bodies(40000, 3, 4), lambda b: nbx.leaves.median_split_leaves(b, 3, 8, reach=0.5))}
+    for name, (b, make) in cases.items():
+        d = tmp_path / name
+        d.mkdir()
+        for n, a in zip(("leaf_offsets", "leaf_bodies", "list_offsets", "list_sources"), make(b)):
+            np.asarray(a, dtype=np.uint32).tofile(str(d / (n + ".u32")))
+        p = subprocess.run([exe, str(d)], capture_output=True, text=True)
+        if p.returncode and "ThreadSanitizer" not in p.stderr and ("FATAL" in p.stderr or "unexpected memory mapping" in p.stderr):
+            pytest.skip("ThreadSanitizer cannot run here: " + p.stderr[-200:])
+        assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stderr[-2000:]
+        assert "blocks" in p.stdout
