@@ -20,7 +20,7 @@
 //    tile's pairs between them; the host cuts the leaf where the two pieces together waste the fewest lanes
 //    (43 targets: 11 x 5 lanes + 32 x 2 lanes = 96 % of the lanes busy; one wave64 with one lane each: 67 %).  Small leaves
 //    (a mean of <= 20 bodies) get one wave per workgroup and no cut;
-//  * structures of SMALL leaves (a mean of <= 8 bodies) are PACKED instead: 4, 8 or 16 leaves share a wave64, every lane holds two
+//  * structures of SMALL leaves (a mean of <= 8 bodies) are PACKED instead: 4, 8, 10 or 16 leaves share a wave64, every lane holds two
 //    targets and streams its share of its leaf's source pairs straight from memory (leaf_pack_kernel below; leaf_plan.h);
 //  * the workgroups are launched longest first, so that the launch drains in a fraction of a mean workgroup's time, and the
 //    blocks of a duration class are dealt to the eight XCDs in consecutive runs (leaf_plan.h order_launch);
@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     __shared__ double osum[3][128];                                // [component][second target? 64 : 0][lane]
     const unsigned lane = threadIdx.x;
     const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
-    const uint32_t w = bp->w, wl = bp->w_log2, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, T = bp->trips;   // wave-uniform
-    const unsigned sub = lane >> wl, lw = lane & (w - 1u);         // w = 1 << wl is 4, 8 or 16
+    const uint32_t w = bp->w, inv_w = bp->inv_w, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, T = bp->trips;   // wave-uniform
+    const unsigned sub = (lane * inv_w) >> 16, lw = lane - sub * w;   // w is 4, 6, 8 or 16: 64 / w leaves; the lanes left over (w = 6: four) hold no leaf
     PackSub my = PackSub{0u, 0u, 0u, 0u};
     if (sub < n_sub) my = a.subs[sub_lo + sub];
     // TWO targets per lane (t and t + W): a loaded source pair is used twice, and the loop's bookkeeping is shared by four terms

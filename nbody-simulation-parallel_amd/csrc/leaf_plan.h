@@ -29,7 +29,7 @@ static_assert(sizeof(LeafBlock) == 32, "LeafBlock is read with scalar loads");
 // ---- packed small leaves (round 4) ----
 // A leaf of a few bodies cannot fill a wave: at 4 bodies per leaf a workgroup's start-up, staging and closing reduction cost ten
 // times its pair arithmetic (0.06 of the fp32 peak in round 3).  Leaves of up to kPackMaxTargets bodies whose list is at most
-// kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 4, 8 or 16 lanes --
+// kPackMaxOps copy runs are therefore PACKED: one wave64 takes K = 64 / w consecutive leaves, each on its own w = 4, 6, 8 or 16 lanes --
 // its own copy runs, P lane groups (two targets per lane; the same P for every leaf of the wave -- leaves are packed with leaves of their size class
 // -- so that every lane runs the same trip count), each lane group streaming its share of its leaf's source pairs straight from
 // memory -- and all of them run the pair loop together.  Everything else (larger leaves, longer lists) keeps the one-leaf
@@ -59,8 +59,12 @@ constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leav
 #ifndef NBX_PACK_SMALL_LANES
 #define NBX_PACK_SMALL_LANES NBX_PACK_TINY_LANES
 #endif
-constexpr uint32_t kPackLanes[4] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, 8u, 16u};
-constexpr uint32_t kPackGroups[4] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, 2u};
+#ifndef NBX_PACK_SIX_LANES
+#define NBX_PACK_SIX_LANES 6    /* A/B: 8 = leaves of 5-6 bodies share the 7-8-body class (8 lanes, two of them idle) */
+#endif
+constexpr int kPackClasses = 5;                 // 1-2, 3-4, 5-6, 7-8, 9-16 bodies
+constexpr uint32_t kPackLanes[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, NBX_PACK_SIX_LANES, 8u, 16u};
+constexpr uint32_t kPackGroups[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, 2u, 2u};
 constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -68,11 +72,11 @@ struct PackSub {                               // one packed leaf
 };
 struct PackBlock {                             // one wave64; read with scalar loads
     uint32_t sub_lo, n_sub;                    // its leaves: subs[sub_lo .. sub_lo + n_sub)
-    uint32_t w, P;                             // lanes per leaf (4 | 8 | 16), lane groups per leaf (2 | 4; 8 in A/B builds): each walks 1 / P of the stream
+    uint32_t w, P;                             // lanes per leaf (4 | 6 | 8 | 16), lane groups per leaf (2 | 4; 8 in A/B builds): each walks 1 / P of the stream
     uint32_t trips;                            // source pairs every lane group walks: ceil(longest stream's pairs / P), rounded up to kPackPairsPerTrip
-    uint32_t w_log2;                           // 2 | 3 | 4
+    uint32_t inv_w;                            // ceil(65536 / w): lane / w = (lane * inv_w) >> 16 for lane < 64 (w need not be a power of two)
     uint32_t longest;                          // longest stream among the wave's leaves, in 16-byte units
-    uint32_t pad_;
+    uint32_t shape;                            // size class of the wave's leaves (host-side sort key: waves of different shapes never share a duration class)
 };
 static_assert(sizeof(PackSub) == 16 && sizeof(PackBlock) == 32, "read with vector / scalar loads");
 
@@ -307,15 +311,16 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     }
     // packed waves.  A lane holds two targets, so a leaf of c bodies takes ceil(c / 2) lanes per lane group.  Leaves are packed
     // with leaves of their own SIZE CLASS -- 1-2 and 3-4 bodies on 4 lanes each (4 and 2 lane groups: 16 leaves to a wave, so that
-    // a wave's start-up and closing reduction, ~400 instructions, are shared by 16 leaves and its loop is twice as long), 5-8
-    // bodies on 8 lanes, 9-16 bodies on 16 lanes (2 groups each); kPackLanes / kPackGroups -- in leaf order within the class, so
-    // that every wave runs the most lane groups its leaves allow (mixed, one 8-body leaf would hold seven smaller ones at two groups).
+    // a wave's start-up and closing reduction, ~400 instructions, are shared by 16 leaves and its loop is twice as long), 5-6
+    // bodies on 6 lanes (10 leaves to a wave; on 8 lanes two of them idle), 7-8 bodies on 8 lanes, 9-16 bodies on 16 lanes (2
+    // groups each); kPackLanes / kPackGroups -- in leaf order within the class, so that every wave runs the most lane groups its
+    // leaves allow (mixed, one 8-body leaf would hold seven smaller ones at two groups).
     std::vector<PackSub>& subs = plan.pack_subs;
     std::vector<PackBlock>& packs = plan.pack_blocks;
     subs.clear();
     packs.clear();
-    auto size_class = [](uint32_t c) -> int { return c <= 2u ? 0 : c <= 4u ? 1 : c <= 8u ? 2 : 3; };
-    std::vector<uint32_t> packable[4];
+    auto size_class = [](uint32_t c) -> int { return c <= 2u ? 0 : c <= 4u ? 1 : c <= 6u ? 2 : c <= 8u ? 3 : 4; };
+    std::vector<uint32_t> packable[kPackClasses];
     for (size_t l = 0; l < n_leaves; ++l) {
         const uint32_t c = leaf_offsets[l + 1] - leaf_offsets[l];
         if (pack_small_leaves && c >= 1u && c <= (uint32_t)kPackMaxTargets && op_off[l + 1] - op_off[l] <= (uint32_t)kPackMaxOps)
@@ -326,18 +331,19 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     // A wave runs as long as its longest leaf: within every window (neighbouring leaves: the locality stays) the leaves are taken
     // longest stream first, so that a wave's leaves are of nearly one length (a 27-cell neighbourhood of ~4.5-body cells: the longest
     // of 8 random ones is 12 % above the mean, of 8 consecutive ones of a sorted 64 2 %).
-    size_t sub_base[5] = {0}, pack_base[5] = {0}, win_base[5] = {0};
-    for (int k = 0; k < 4; ++k) {
+    size_t sub_base[kPackClasses + 1] = {0}, pack_base[kPackClasses + 1] = {0}, win_base[kPackClasses + 1] = {0};
+    for (int k = 0; k < kPackClasses; ++k) {
         const size_t per_wave = 64u / kPackLanes[k];
         sub_base[k + 1] = sub_base[k] + packable[k].size();
         pack_base[k + 1] = pack_base[k] + (packable[k].size() + per_wave - 1u) / per_wave;
         win_base[k + 1] = win_base[k] + (packable[k].size() + kPackWindowWaves * per_wave - 1u) / (kPackWindowWaves * per_wave);
     }
-    subs.resize(sub_base[4]);
-    packs.resize(pack_base[4]);
-    const unsigned pack_threads = win_base[4] >= 64u ? n_threads : 1u;
+    subs.resize(sub_base[kPackClasses]);
+    packs.resize(pack_base[kPackClasses]);
+    const size_t n_windows = win_base[kPackClasses];
+    const unsigned pack_threads = n_windows >= 64u ? n_threads : 1u;
     auto pack_windows = [&](unsigned t) {
-        const size_t w_lo = win_base[4] * t / pack_threads, w_hi = win_base[4] * (t + 1u) / pack_threads;
+        const size_t w_lo = n_windows * t / pack_threads, w_hi = n_windows * (t + 1u) / pack_threads;
         for (size_t wi = w_lo; wi < w_hi; ++wi) {
             int k = 0;
             while (wi >= win_base[k + 1]) ++k;
@@ -353,7 +359,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             for (size_t i0 = i; i0 < e; i0 += per_wave) {
                 PackBlock b{};
                 b.sub_lo = (uint32_t)(sub_base[k] + i0);
-                b.w = w; b.w_log2 = w == 4u ? 2u : w == 8u ? 3u : 4u; b.P = P;
+                b.w = w; b.inv_w = (65536u + w - 1u) / w; b.P = P; b.shape = (uint32_t)k;
                 uint32_t longest = 0;
                 for (size_t j = i0; j < e && j < i0 + per_wave; ++j) {
                     const uint32_t l = leaves_k[j];
@@ -397,7 +403,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     section(2);
     // waves of different shapes (lanes per leaf, lane groups) never share a duration class: equal trips are not equal durations, and
     // the blocks of a class are dealt to the XCDs side by side
-    order_launch(packs, [](const PackBlock& b) -> uint32_t { return (b.trips < (1u << 28) ? b.trips : (1u << 28)) * 8u + (b.w_log2 - 2u) * 2u + (b.P > 2u ? 1u : 0u); });
+    order_launch(packs, [](const PackBlock& b) -> uint32_t { return (b.trips < (1u << 28) ? b.trips : (1u << 28)) * 8u + b.shape; });
     order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
     section(3);
 

@@ -25,7 +25,7 @@ def _build_planner(tmp_path_factory, name, *defines):
         out = {k: np.fromfile(os.path.join(workdir, k + ".u32"), dtype=np.uint32)
                for k in ("unit_off", "pslot_body", "ops", "op_off", "blocks", "pack_subs", "pack_blocks")}
         out["pack_subs"] = out["pack_subs"].reshape(-1, 4)      # op_lo, op_n, first, count
-        out["pack_blocks"] = out["pack_blocks"].reshape(-1, 8)  # sub_lo, n_sub, w, P, trips, w_log2, longest, -
+        out["pack_blocks"] = out["pack_blocks"].reshape(-1, 8)  # sub_lo, n_sub, w, P, trips, inv_w, longest, shape
         out["waves"] = int(p.stdout.split()[1])
         out["ops"] = out["ops"].reshape(-1, 2)          # (end, base)
         out["blocks"] = out["blocks"].reshape(-1, 8)    # op_lo, op_n, key, -, first0, count0, first1, count1
@@ -69,7 +69,7 @@ def _structure(seed, sizes, list_len):
     return lo, lb, so, ss
 
 
-def packs_w_log2(plan, sub_lo):
+def packs_inv_w(plan, sub_lo):
     rows = plan["pack_blocks"]
     return int(rows[rows[:, 0] == sub_lo][0, 5])
 
@@ -124,16 +124,17 @@ def _check(plan, lo, lb, so, ss):
     n_ops_of = np.diff(op_off.astype(np.int64))
     seen_sub = np.zeros(subs.shape[0], dtype=np.int64)
     for sub_lo, n_sub, w, P, trips, _, longest, _ in packs:
-        assert w in (4, 8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
+        assert w in (4, 6, 8, 16) and 1 <= n_sub <= 64 // w and 1 <= P <= 8
         mine = subs[sub_lo:sub_lo + n_sub]
         seen_sub[sub_lo:sub_lo + n_sub] += 1
         assert (mine[:, 3] >= 1).all() and (mine[:, 3] <= w).all() and (mine[:, 1] <= 32).all()
         # leaves share a wave with leaves of their size class (a lane holds two targets): 1-2 and 3-4 bodies on 4 lanes (4 and 2 lane
-        # groups), 5-8 bodies on 8 lanes, 9-16 bodies on 16 lanes (2 groups each)
-        cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 8 else 3
+        # groups), 5-6 bodies on 6 lanes, 7-8 bodies on 8 lanes, 9-16 bodies on 16 lanes (2 groups each)
+        cls = lambda c: 0 if c <= 2 else 1 if c <= 4 else 2 if c <= 6 else 3 if c <= 8 else 4
         k = cls(mine[0, 3])
-        assert all(cls(c) == k for c in mine[:, 3]) and w == (4, 4, 8, 16)[k] and P == (4, 2, 2, 2)[k]
-        assert (-(-mine[:, 3] // 2) * P <= w).all() and 1 << packs_w_log2(plan, sub_lo) == w
+        assert all(cls(c) == k for c in mine[:, 3]) and w == (4, 4, 6, 8, 16)[k] and P == (4, 2, 2, 2, 2)[k]
+        assert (-(-mine[:, 3] // 2) * P <= w).all() and packs_inv_w(plan, sub_lo) == -(-65536 // w)
+        assert all((lane * packs_inv_w(plan, sub_lo)) >> 16 == lane // w for lane in range(64))
         streams = [int(ops[o + k - 1][0]) if k else 0 for o, k, _, _ in mine]
         # every lane group walks the same number of source pairs: its share of the longest stream, an even number (the loop takes two at a time)
         assert longest == max(streams) and longest % 2 == 0
