@@ -19,7 +19,7 @@ all: lib oracle nbody_sim
 lib: $(LIB)
 
 OBJS := $(CSRC)/force_kernel.o $(CSRC)/force_launch.o \
-        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o $(CSRC)/leaf_pair_kernel.o $(CSRC)/close_hash.o
+        $(CSRC)/state_kernels.o $(CSRC)/nbx_api.o $(CSRC)/nbx_node.o $(CSRC)/leaf_pair_kernel.o $(CSRC)/close_hash.o $(CSRC)/measure_kernels.o
 # name of the force-kernel variant used when the caller does not pick one
 # (round 4: the three-level summation build -- same pair arithmetic, fp32 errors ~3x smaller for +1.5 % time)
 DEFAULT_VARIANT ?= fastpk3l_t8_w3_u4
@@ -43,10 +43,13 @@ $(CSRC)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h 
 $(CSRC)/nbx_node.o: $(CSRC)/nbx_node.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h
-	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c $< -o $@
+$(CSRC)/measure_kernels.o: $(CSRC)/measure_kernels.hip $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/leaf_plan.h $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
+$(CSRC)/close_hash.o: $(CSRC)/close_hash.hip $(CSRC)/nbx_internal.h $(CSRC)/device_sort.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/leaf_pair_kernel.o: $(CSRC)/leaf_pair_kernel.hip $(CSRC)/leaf_plan.h $(CSRC)/leaf_plan_device.h $(CSRC)/device_sort.h $(CSRC)/nbx_internal.h $(CSRC)/nbx_ctx.h include/nbody_hip.h
 	$(HIPCC) $(HIPFLAGS) $(LEAF_DEFS) -c $< -o $@
 
 $(LIB): $(OBJS) $(CSRC)/libnbody_hip.map

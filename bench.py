@@ -31,7 +31,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 FLOP_PER_INTERACTION = 20          # SURVEY 8d convention (3 sub, 5 r^2, rcp, 3 mul, 6 fma-acc, 2 guard)
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = FP32 matrix
 HBM_PEAK_GBPS = 8000.0
-PROFILE_ROUND = "r4"               # profiles/<round>/pmc_force_kernel.json: the committed PMC passes of this command
+PROFILE_ROUNDS = ("r5", "r4")      # profiles/<round>/pmc_force_kernel.json, newest first: the committed PMC passes of this command
+SHADER_PEAK_MHZ = 2400.0           # MI355X_MICROARCH.md: the clock the 157.3 TFLOP/s figure assumes
 
 
 def host_facts():
@@ -78,7 +79,7 @@ def cpu_baseline_child(threads, n_s, dim, seed):
                           "value": n_s * (n_s - 1) / dt}), flush=True)
 
 
-def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
+def cpu_baseline(n_bodies, dim, seed, budget_s=10.0, n_sample=0):
     """Reported baseline (not the target): the reference's own brute_force_omp_n_body_2 object code
     (oracle/_ref, kind "reference") or the oracle port of it (kind "port") on a bounded sample of
     the same workload, timed on this host's cores: at 16 threads (the box's CPU share for one GPU, the primary
@@ -100,14 +101,17 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=10.0):
     rate = rows.size * n_bodies / (time.perf_counter() - t0)
     if have_reference():
         try:
-            n_s = int(min(n_bodies, max(4096, (rate * budget_s) ** 0.5)))
-            n_s = 1 << (n_s.bit_length() - 1)
+            if n_sample:    # --cpu-baseline-n: SURVEY 8(d)'s sizes (262,144 or the full N); minutes of host time, never the driver's default
+                n_s = int(min(n_bodies, n_sample))
+            else:
+                n_s = int(min(n_bodies, max(4096, (rate * budget_s) ** 0.5)))
+                n_s = 1 << (n_s.bit_length() - 1)
             runs = []
             counts = [threads] + ([host["physical_cores_usable"]] if host["physical_cores_usable"] > threads else [])
             for c in counts:
                 env = dict(os.environ, OMP_NUM_THREADS=str(c), PARLAY_NUM_THREADS=str(c), OMP_PROC_BIND="spread", OMP_PLACES="cores")
                 p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(c), "--bodies", str(n_s),
-                                    "--dim", str(dim), "--seed", str(seed)], env=env, capture_output=True, text=True, timeout=600)
+                                    "--dim", str(dim), "--seed", str(seed)], env=env, capture_output=True, text=True, timeout=3000 if n_sample else 600)
                 if p.returncode:
                     raise RuntimeError(p.stderr[-300:])
                 runs += [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
@@ -193,6 +197,34 @@ def leaf_pair_roofline(device):
             "back_to_back": {"kernel_ms": warm, "achieved": tflops(warm), "frac": tflops(warm) / 157.3,
                              "means": "mean of launches 151-300 of 300 back to back (nbx_leaf_plan_time_kernel): clocks up"},
             "at_the_reference_trees_leaf_sizes": by_size}
+
+
+def launched_kernel_symbol(variant_name, dim, refine_tol):
+    """Demangled symbol of the force kernel a run with this variant / precision mode launches (from the library; no device)."""
+    import nbody_amd as nbx
+    capi = nbx.package.capi
+    try:
+        return capi.variant_kernel_symbol(variant_name, dim, bool(refine_tol))
+    except nbx.NbxError:       # a variant without a mixed-mode build runs its plain kernel whatever the tolerance
+        return capi.variant_kernel_symbol(variant_name, dim, False)
+
+
+def pmc_traffic(pmc, launched):
+    """HBM bytes per launch of kernel `launched` from a profiles/<round>/pmc_force_kernel.json (tools/summarize_prof.py), or None
+    when the profile is of another kernel.  Units and gfx950 corrections as the guide's HBM section prescribes: KB -> bytes;
+    FETCH_SIZE under-reports coalesced streaming reads by 2, confirmed for THIS path's streams by the helper kernels of the same
+    profile whose byte counts are known exactly ("calibration")."""
+    if not (pmc["pmc_fetch"]["kernel"]["Kernel_Name"] == launched == pmc["pmc_write"]["kernel"]["Kernel_Name"]):
+        return None
+    fetch_kb = pmc["pmc_fetch"]["per_launch_mean"]["FETCH_SIZE"]
+    write_kb = pmc["pmc_write"]["per_launch_mean"]["WRITE_SIZE"]
+    cal = pmc.get("calibration", {})
+    ff = [v["FETCH_SIZE"]["true_over_reported"] for v in cal.values() if "FETCH_SIZE" in v]
+    wf = [v["WRITE_SIZE"]["true_over_reported"] for v in cal.values() if "WRITE_SIZE" in v]
+    f_fetch = sum(ff) / len(ff) if ff else 2.0      # guide: x2 on gfx950 for coalesced streaming reads
+    f_write = sum(wf) / len(wf) if wf else 1.0
+    return {"bytes": (f_fetch * fetch_kb + f_write * write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb,
+            "f_fetch": f_fetch, "f_write": f_write}
 
 
 def _norm(a):
@@ -344,11 +376,27 @@ def main():
                          "suspects; default 1e-5 = the north star's tolerance, met for every body); 0 = plain fp32")
     ap.add_argument("--no-all-bodies", action="store_true", help="skip the device-side check of every body against the strict fp64 kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-n", type=int, default=0,
+                    help="bodies of the CPU baseline's sample (0: automatic, ~10 s of host time = 131,072 on a GPU box's 16 threads; "
+                         "SURVEY 8(d) names 262,144 or the full N -- minutes, for profiles/, not for the driver's default run)")
     ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child, args.bodies, args.dim, args.seed)
         return
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: this process has made no GPU call (and makes none): it starts the N ranks as a CHILD
+        # `python -m torch.distributed.run`, which inherits stdout (rank 0's one JSON line goes straight through), waits, and
+        # exits with the child's status.  Never an exec: a process that has touched the GPU must not be replaced on this pool.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, NBODY_BENCH_LAUNCHER="bench.py started torch.distributed.run as a child process")).returncode)
 
     import numpy as np
     import torch
@@ -368,9 +416,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world != args.gpus:   # under a launcher the launcher's world size is the truth
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -429,6 +475,13 @@ def main():
             dist.destroy_process_group()
             sys.exit(3)
 
+    # the force kernel's workgroups stamp the shader clock they held (nbx_ctx_enable_clock_stamps: two scalar clock reads and
+    # one 16-byte store per workgroup of ~40 ms); on before the warm-up so that the captured step carries it
+    clock_stamps = True
+    try:
+        be.ctx.enable_clock_stamps(True)
+    except nbx.NbxError:   # a variant without stamps was asked for
+        clock_stamps = False
     for _ in range(args.warmup):
         system.step(args.dt, G, 1)
     sync_all()
@@ -453,6 +506,20 @@ def main():
         elapsed = float(t.item())
     kern_ms, launches = be.kernel_time()  # HIP events on the stream the kernels ran on
     refine_ms_total = be.ctx.refine_time()  # the mixed mode's kernels behind those launches (third event of each evaluation)
+    held = None
+    if clock_stamps:
+        try:
+            held = be.ctx.shader_clock()     # the LAST timed force launch's workgroups (this rank)
+        except nbx.NbxError:
+            held = None
+        be.ctx.enable_clock_stamps(False)
+    ceiling = None
+    if rank == 0:   # the same chip, straight after the timed steps (still warm): a pure v_pk_fma_f32 stream for ~50 ms
+        try:
+            tf, mhz = nbx.package.capi.measure_valu_ceiling(local_rank, 50.0)
+            ceiling = {"tflops": tf, "shader_mhz": mhz}
+        except nbx.NbxError:
+            ceiling = None
 
     result = None
     if rank == 0:
@@ -485,7 +552,16 @@ def main():
                          "interactions_per_launch": my_pairs_per_launch / launches_per_step,
                          "whole_step_frac": value / world * FLOP_PER_INTERACTION / 1e12 / PEAK_FP32_TFLOPS if world == 1 else None,
                          "mixed_mode_kernels_ms_per_step": refine_ms_total / max(args.steps, 1),
-                         "note": "arithmetic intensity ~7.5e5 flop/B: HBM-light; measured ceiling of a pure v_pk_fma_f32 stream on this chip is 131 TFLOP/s (profiles/r1c/ubench_banks.txt)",
+                         # what THIS box held during THIS run: frac above is against 157.3 TFLOP/s = 2.4 GHz x one packed FMA per
+                         # lane pair per cycle; the chip clocks lower under a dense VALU load, and by how much differs from box to box
+                         "shader_mhz": held["median_mhz"] if held else None,
+                         "shader_mhz_detail": dict(held, source="in-kernel stamps (s_memtime / s_memrealtime) of the last timed force launch, "
+                                                   "one pair per workgroup, nbx_ctx_shader_clock") if held else "not measured (kernel variant without stamps)",
+                         "frac_at_held_clock": achieved_tflops / (PEAK_FP32_TFLOPS * held["median_mhz"] / SHADER_PEAK_MHZ) if held else None,
+                         "this_box_ceiling": dict(ceiling, kernel="pure v_pk_fma_f32 stream, 16 chains per lane, 3 waves per SIMD, ~50 ms right after the "
+                                                  "timed steps (nbx_measure_valu_ceiling)") if ceiling else None,
+                         "frac_of_this_box_ceiling": achieved_tflops / ceiling["tflops"] if ceiling else None,
+                         "note": "arithmetic intensity ~7.5e5 flop/B: HBM-light; compare runs across boxes by frac_at_held_clock / frac_of_this_box_ceiling, not by frac",
                          "hbm": {"algorithmic_bytes_per_launch": 28.0 * N / world if world == 1 else (16.0 * N + 12.0 * system.layout.count),
                                  "achieved_GBps": (28.0 * N if world == 1 else (16.0 * N + 12.0 * system.layout.count)) / kern_s_per_step / 1e9,
                                  "peak_GBps": HBM_PEAK_GBPS}},
@@ -493,36 +569,35 @@ def main():
     if rank == 0 and world == 1 and N == 1 << 20 and args.dim == 3:
         # HBM traffic of the force kernel per launch: PMC counters cannot be read from inside the process; they come from
         # the committed rocprofv3 --pmc passes of this same command (tools/profile_bench.sh -> tools/summarize_prof.py ->
-        # profiles/<round>/pmc_force_kernel.json), and only if that profile is of the kernel that just ran -- otherwise the
-        # field stays null and says why.  Units and gfx950 corrections as the guide's HBM section prescribes: KB -> bytes;
-        # FETCH_SIZE under-reports coalesced streaming reads by 2 on gfx950 -- confirmed for THIS path's 4-/8-byte-per-lane
-        # streams by the helper kernels of the same profile, whose byte counts are known exactly (classify_*: 12 B/body,
-        # kick_drift: (12 S + 56) B/body read, 60 B/body written: "calibration" in the json, true/reported = 2.00 and 1.00).
-        qs = 1 if args.refine else 0   # mixed mode (the default) runs the build that also writes the spread sums
-        kernel_of = {"fastpk3l_t8_w3_u4": f"accel_fast3l_kernel<3, 4, 3, 4, 64, {qs}, 0>", "fastpk_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 1, {qs}>", "fastpk1r_t8_w3_u4": f"accel_fast_pk_kernel<3, 4, 3, 4, 1, 0, 1, 1, {qs}>",
-                     "lds_t1_w8_exact_u8": "accel_lds_kernel<3, 1, 8, 8>", "strict_f64_t4": "accel_f64_kernel<3, 4, 2, 2, 2, 0, 0>"}
-        prof = os.path.join("profiles", PROFILE_ROUND, "pmc_force_kernel.json")
-        try:
-            with open(os.path.join(ROOT, prof)) as f:
-                pmc = json.load(f)
-            profiled = pmc["pmc_fetch"]["kernel"]["Kernel_Name"]
-            if kernel_of.get(variant_name, "?") in profiled and profiled == pmc["pmc_write"]["kernel"]["Kernel_Name"]:
-                fetch_kb = pmc["pmc_fetch"]["per_launch_mean"]["FETCH_SIZE"]
-                write_kb = pmc["pmc_write"]["per_launch_mean"]["WRITE_SIZE"]
-                cal = pmc.get("calibration", {})
-                ff = [v["FETCH_SIZE"]["true_over_reported"] for v in cal.values() if "FETCH_SIZE" in v]
-                wf = [v["WRITE_SIZE"]["true_over_reported"] for v in cal.values() if "WRITE_SIZE" in v]
-                f_fetch = sum(ff) / len(ff) if ff else 2.0      # guide: x2 on gfx950 for coalesced streaming reads
-                f_write = sum(wf) / len(wf) if wf else 1.0
-                result["roofline"]["traffic"] = (f_fetch * fetch_kb + f_write * write_kb) * 1024.0
-                result["roofline"]["traffic_source"] = (f"{prof}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) of this command and this "
-                                                        f"kernel, per launch: {fetch_kb / 1024:.0f} MiB x {f_fetch:.2f} fetched + {write_kb / 1024:.0f} MiB "
-                                                        f"x {f_write:.2f} written; factors calibrated on the helper kernels of the same profile "
-                                                        "(known byte counts), = the guide's gfx950 FETCH_SIZE correction")
-            else:
-                result["roofline"]["traffic_source"] = f"stale: {prof} is a profile of '{profiled}', the run used variant {variant_name}"
-        except Exception as e:
-            result["roofline"]["traffic_source"] = f"no PMC profile available ({prof}: {e.__class__.__name__})"
+        # profiles/<round>/pmc_force_kernel.json), and only if that profile is of the kernel that just ran -- identified by the
+        # symbol the LIBRARY reports for it (nbx_variant_kernel_symbol: the registered name, demangled as rocprofv3 prints it),
+        # no hand-kept table to go stale when a template parameter is added -- otherwise the field stays null and says why.
+        launched = launched_kernel_symbol(variant_name, args.dim, args.refine)
+        result["roofline"]["kernel_symbol"] = launched
+        seen = []
+        for rnd in PROFILE_ROUNDS:
+            prof = os.path.join("profiles", rnd, "pmc_force_kernel.json")
+            try:
+                with open(os.path.join(ROOT, prof)) as f:
+                    pmc = json.load(f)
+                t = pmc_traffic(pmc, launched)
+            except Exception as e:
+                seen.append(f"{prof}: {e.__class__.__name__}")
+                continue
+            if t is None:
+                seen.append(f"{prof} is a profile of '{pmc['pmc_fetch']['kernel']['Kernel_Name']}'")
+                continue
+            result["roofline"]["traffic"] = t["bytes"]
+            result["roofline"]["traffic_over_algorithmic"] = t["bytes"] / (28.0 * N)
+            result["roofline"]["traffic_source"] = (f"{prof}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) of this command and this "
+                                                    f"kernel, per launch: {t['fetch_kb'] / 1024:.0f} MiB x {t['f_fetch']:.2f} fetched + {t['write_kb'] / 1024:.0f} MiB "
+                                                    f"x {t['f_write']:.2f} written; factors calibrated on the helper kernels of the same profile "
+                                                    "(known byte counts), = the guide's gfx950 FETCH_SIZE correction")
+            break
+        else:
+            result["roofline"]["traffic_source"] = f"no committed PMC profile of the kernel this run launched ('{launched}'): " + "; ".join(seen)
+    if rank == 0:
+        result["launcher"] = os.environ.get("NBODY_BENCH_LAUNCHER", "torch.distributed.run started by the caller" if "WORLD_SIZE" in os.environ else "single process")
     if rank == 0 and world > 1:
         # self-description of the N > 1 path (never executed on hardware before the driver's scaling run)
         result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
@@ -558,7 +633,7 @@ def main():
                     other = {"leaf_pair": leaf_pair_roofline(local_rank)}
                 except Exception as e:   # never at the expense of the headline line
                     other = {"leaf_pair": f"not measured: {e.__class__.__name__}: {e}"}
-            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed)   # rank 0's host cores, after the last collective
+            result["cpu_baseline"] = cpu_baseline(N, args.dim, args.seed, n_sample=args.cpu_baseline_n)   # rank 0's host cores, after the last collective
             if other is not None:
                 result["other_kernels"] = other
         print(json.dumps(result), flush=True)

@@ -40,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NBX_ABI_VERSION 4   /* 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only); 4: mixed mode ON by default (nbx_set_default_refine), nbx_brute_force_forces_ex, nbx_node_refine_stats, the leaf plan (nbx_leaf_plan_*); nbx_leaf_pair_forces no longer reads NBX_LEAF_TIMING_REPS */
+#define NBX_ABI_VERSION 5   /* 5: + the measurement entries nbx_variant_kernel_symbol, nbx_ctx_enable_clock_stamps, nbx_ctx_shader_clock, nbx_measure_valu_ceiling (additions only); 2: + nbx_leaf_pair_forces, nbx_*_set_softening, nbx_*_set_law, nbx_node_verify_exchange, nbx_ctx_close_set_mode, nbx_ctx_kick_drift2, nbx_*_step_kdk; 3: + nbx_*_set_refine, nbx_ctx_refine_stats, the strict fp64 kernel variant (additions only); 4: mixed mode ON by default (nbx_set_default_refine), nbx_brute_force_forces_ex, nbx_node_refine_stats, the leaf plan (nbx_leaf_plan_*); nbx_leaf_pair_forces no longer reads NBX_LEAF_TIMING_REPS */
 
 /* status codes */
 enum {
@@ -358,6 +358,26 @@ int nbx_ctx_kernel_time(nbx_ctx* ctx, float* mean_ms, int* launches);
 /* Device time in ms (total, not mean) of the mixed mode's select / fp64 re-evaluation / fold kernels that followed the force-kernel
  * launches covered by the LAST nbx_ctx_kernel_time call (graph-replayed steps carry theirs inside the whole-step time). */
 int nbx_ctx_refine_time(nbx_ctx* ctx, float* total_ms);
+
+/* ---- MEASUREMENT entries (bench.py, tools/; nothing on the product path calls them) ----------------------------------
+ * The symbol of the force kernel that an evaluation with `variant` (nbx_ctx_effective_tuning) launches for `dim`, in its plain
+ * (mixed_mode = 0) or mixed-mode (1: also writes the spread sums) reference-law build, demangled as rocprofv3 prints it (e.g.
+ * "void nbx::(anonymous namespace)::accel_fast3l_kernel<3, 4, 3, 4, 64, 1, 0, 1>(nbx::KArgs)"): what ties a live run to the
+ * committed profiles/ of the same kernel.  Needs no device.  len >= 16 (NBX_ERR_INVALID otherwise; the name is truncated to fit). */
+int nbx_variant_kernel_symbol(int variant, int dim, int mixed_mode, char* buf, size_t len);
+/* In-kernel clock stamps: while on, every workgroup of the default (three-level) force kernel reads the shader clock
+ * (s_memtime) and the constant 100 MHz clock (s_memrealtime) around its work -- two scalar loads and one 16-byte store per
+ * workgroup of ~40 ms; no measurable cost (profiles/r5) -- and nbx_ctx_shader_clock reports, for the LAST stamped launch, the
+ * median / smallest / largest of  d s_memtime / d s_memrealtime x 100 MHz  over its workgroups: the clock the chip actually
+ * held under THIS kernel on THIS box, which is what a roofline fraction quoted at the 2.4 GHz peak cannot say.
+ * NBX_ERR_STATE when the kernel that would run carries no stamps (non-default variants) or nothing stamped has run.
+ * nbx_ctx_shader_clock synchronises the stream.  Any out pointer may be NULL. */
+int nbx_ctx_enable_clock_stamps(nbx_ctx* ctx, int on);
+int nbx_ctx_shader_clock(nbx_ctx* ctx, double* median_mhz, double* min_mhz, double* max_mhz, int* workgroups);
+/* The same box's ceiling: a pure v_pk_fma_f32 stream (16 independent chains per lane, three waves per SIMD on every CU)
+ * for about target_ms (1..2000) on `device`; *tflops = what it achieved (4 flop per lane-instruction), *shader_mhz = the
+ * clock it held.  The guide's 157.3 TFLOP/s assumes 2.4 GHz and one packed FMA per cycle per lane pair. */
+int nbx_measure_valu_ceiling(int device, double target_ms, double* tflops, double* shader_mhz);
 
 /* ---- single-process multi-GPU node ---------------------------------------------------------------
  * The reference is single-process, single-device; this is new.  One context per rank

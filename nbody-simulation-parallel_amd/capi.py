@@ -82,6 +82,10 @@ ABI = [
     ("nbx_default_variant", _i, []),
     ("nbx_ctx_kernel_time", _i, [_vp, _pf, _pi]),
     ("nbx_ctx_refine_time", _i, [_vp, _pf]),
+    ("nbx_variant_kernel_symbol", _i, [_i, _i, _i, _c.c_char_p, _sz]),
+    ("nbx_ctx_enable_clock_stamps", _i, [_vp, _i]),
+    ("nbx_ctx_shader_clock", _i, [_vp, _pd, _pd, _pd, _pi]),
+    ("nbx_measure_valu_ceiling", _i, [_i, _d, _pd, _pd]),
     ("nbx_node_create", _i, [_c.POINTER(_vp), _i, _pi, _i, _sz, _i]),
     ("nbx_node_destroy", _i, [_vp]),
     ("nbx_node_exchange_mode", _i, [_vp, _pi]),
@@ -163,6 +167,24 @@ def device_count() -> int:
     n = ctypes.c_int(0)
     _check(lib, lib.nbx_device_count(ctypes.byref(n)), "nbx_device_count")
     return n.value
+
+
+def measure_valu_ceiling(device: int = 0, target_ms: float = 50.0) -> Tuple[float, float]:
+    """(TFLOP/s, shader MHz) of a pure v_pk_fma_f32 stream on `device` for ~target_ms: this box's fp32 VALU ceiling."""
+    lib = load_library()
+    tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _check(lib, lib.nbx_measure_valu_ceiling(int(device), float(target_ms), ctypes.byref(tf), ctypes.byref(mhz)), "nbx_measure_valu_ceiling")
+    return tf.value, mhz.value
+
+
+def variant_kernel_symbol(variant, dim: int = 3, mixed_mode: bool = True) -> str:
+    """Demangled symbol (as rocprofv3 prints it) of the force kernel `variant` (id or name) launches; needs no device."""
+    lib = load_library()
+    if isinstance(variant, str):
+        variant = variants().index(variant)
+    buf = ctypes.create_string_buffer(512)
+    _check(lib, lib.nbx_variant_kernel_symbol(int(variant), int(dim), 1 if mixed_mode else 0, buf, 512), "nbx_variant_kernel_symbol")
+    return buf.value.decode()
 
 
 def variants():
@@ -493,6 +515,15 @@ class Context:
         self._ck(self.lib.nbx_ctx_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(cnt)), "nbx_ctx_kernel_time")
         return ms.value, cnt.value
 
+
+    def enable_clock_stamps(self, on: bool = True):
+        self._ck(self.lib.nbx_ctx_enable_clock_stamps(self.h, 1 if on else 0), "nbx_ctx_enable_clock_stamps")
+
+    def shader_clock(self) -> dict:
+        """Shader clock held by the last stamped force launch: median / min / max MHz over its workgroups."""
+        med, lo, hi, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
+        self._ck(self.lib.nbx_ctx_shader_clock(self.h, ctypes.byref(med), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(n)), "nbx_ctx_shader_clock")
+        return {"median_mhz": med.value, "min_mhz": lo.value, "max_mhz": hi.value, "workgroups": n.value}
 
     def refine_time(self) -> float:
         """Total ms of the mixed mode's kernels behind the evaluations the last kernel_time() call covered."""

@@ -553,6 +553,8 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast_pk_kernel(KArgs a) {
 // REGSUMS = 1: the fp64 slice sums stay in registers instead (48 more VGPRs: two waves per SIMD -- the two-level kernel loses
 // 0.4 % at that occupancy, profiles/r2/variants_shape.txt); with WAVES = 2 the source tile is double-buffered again (one barrier
 // per tile), with WAVES = 3 the 52 KB of LDS per workgroup leave room for a single tile buffer only (two barriers per tile).
+// Measured and lost in round 5 (profiles/r5/variants_half_tile.txt: 231.7 against 230.6 ms, bitwise-equal forces): filling and
+// consuming the single tile buffer in two halves, so that none of the two barriers per tile follows another back to back.
 template <int D, int PAIRS, int WAVES, int UNROLL, int LB, int QS, int REGSUMS, int PEEL = 1>
 __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     constexpr int TPL = 2 * PAIRS;
@@ -569,6 +571,14 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
     if (bx < a.close_blocks) {   // the launch's extra workgroups: guarded evaluation of the close set (they keep no slice sums)
         close_set_path<D>(a, *reinterpret_cast<float4 (*)[2][kTile]>(smem), bx, by);
         return;
+    }
+    // measurement only (a.clk is null in every other launch; a uniform branch on a kernel argument, four SGPRs): the shader
+    // clock this workgroup held = d s_memtime / d s_memrealtime x 100 MHz (nbx_ctx_shader_clock)
+    unsigned long long clk_r0 = 0, clk_t0 = 0;
+    if (a.clk) {
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+        clk_t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) here, so that the loop's LDS waits stay counted
     }
     float4* __restrict__ tile = reinterpret_cast<float4*>(smem);
     double2* __restrict__ sums = reinterpret_cast<double2*>(smem + kOwnTileBytes);
@@ -689,6 +699,14 @@ __global__ __launch_bounds__(256, WAVES) void accel_fast3l_kernel(KArgs a) {
             } else if (QS) {
                 qout[i] = __builtin_inff();   // a close-set target of this pass keeps no spread sum: it is always a suspect
             }
+        }
+    }
+    if (a.clk) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            a.clk[2 * wg] = t1 - clk_t0;
+            a.clk[2 * wg + 1] = r1 - clk_r0;
         }
     }
 }
@@ -1020,40 +1038,15 @@ __global__ __launch_bounds__(256, 8) void potential_kernel(KArgs a) {
 #define NBX_FAST3L(PAIRS, WAVES, UNROLL, LB, REGSUMS) \
     accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 0, REGSUMS>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 0, REGSUMS>, 1, 0, 0, \
     nullptr, nullptr, nullptr, nullptr, \
-    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, 2, 0
+    accel_fast3l_kernel<2, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, accel_fast3l_kernel<3, PAIRS, WAVES, UNROLL, LB, 1, REGSUMS>, 2, 0, 1
 
 const KernelVariant kVariants[] = {
     {"fastpk_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 0)},        // two reciprocals per target pair
     {"fastpk3l_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 64, 0)},   // + three-level summation (64-source blocks, tile, fp64 slice sums in LDS; single tile buffer)
-#ifdef NBX_AB_3L   /* measured and lost, profiles/r4/variants_3l_*.txt: 222.6-225.4 ms against 221.6 */
-    {"fastpk3l_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 0)},   // two waves per SIMD: double-buffered tiles, fp64 slice sums in LDS
-    {"fastpk3lr_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 64, 1)},  // two waves per SIMD: double-buffered tiles, fp64 slice sums in registers
-    {"fastpk3lr32_t8_w2_u4", 8, NBX_FAST3L(4, 2, 4, 32, 1)},// the same with 32-source blocks
-    {"fastpk3l32_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 32, 0)}, // 32-source blocks: errors another 1.2x smaller, +1.1 % time
-    {"fastpk3l_t8_w3_u4_nopeel", 8, accel_fast3l_kernel<2, 4, 3, 4, 64, 0, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 0, 0, 0>, 1, 0, 0, nullptr, nullptr, nullptr, nullptr,
-     accel_fast3l_kernel<2, 4, 3, 4, 64, 1, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 1, 0, 0>, 2, 0},   // block sums zeroed instead of started by the first source
-    {"fastpk3l_t8_w3_u4_qtile", 8, accel_fast3l_kernel<2, 4, 3, 4, 64, 0, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 0, 0>, 1, 0, 0, nullptr, nullptr, nullptr, nullptr,
-     accel_fast3l_kernel<2, 4, 3, 4, 64, 2, 0>, accel_fast3l_kernel<3, 4, 3, 4, 64, 2, 0>, 2, 0},         // Q from the tile sums instead of the block sums
-    {"fastpk3l128_t8_w3_u4", 8, NBX_FAST3L(4, 3, 4, 128, 0)},   // 128-source blocks: half the block flushes, errors 1.4x larger
-#endif
     {"fastpk1r_t8_w3_u4", 8, NBX_FAST(4, 3, 4, 1)},      // one reciprocal per target pair (needs the extent precondition)
-#ifdef NBX_AB_HI_SEL
-    {"fastpk_t8_w3_u4_mov", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},
-    {"fastpk_t8_w3_u2", 8, NBX_FAST(4, 3, 2, 0)},
-    {"fastpk_t8_w3_u8", 8, NBX_FAST(4, 3, 8, 0)},
-    {"fastpk_t8_w2_u4", 8, NBX_FAST(4, 2, 4, 0)},
-    {"fastpk_t4_w6_u4", 4, NBX_FAST(2, 6, 4, 0)},
-    {"fastpk_t16_w1_u2", 16, NBX_FAST(8, 1, 2, 0)},
-    {"fastpk_t8_w3_u4_noxcd", 8, accel_fast_pk_kernel<2, 4, 3, 4, 0, 0, 1, 0>, accel_fast_pk_kernel<3, 4, 3, 4, 0, 0, 1, 0>, 1, 256, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0},
-#endif
     {"lds_t1_w8_exact_u8", 1, NBX_LDS(1, 8, 8)},         // per-pair compare-and-select guard, self-contained
     {"strict_f64_t4", 4, NBX_F64(4, 2, 2, 2, 0)},        // fp64 throughout (the reference's arithmetic type); ~2.5x the fast kernel's time
     {"strict_f64_t4_mag", 4, NBX_F64(4, 2, 2, 2, 1)},    // + the magnitude sums S_i = sum_j |a_ij| (nbx_ctx_get_aux): the checker's build
-#ifdef NBX_AB_F64
-    {"strict_f64_t4_nr1", 4, NBX_F64(4, 2, 2, 1, 0)},
-    {"strict_f64_t2", 2, NBX_F64(2, 4, 4, 2, 0)},
-    {"strict_f64_t8", 8, NBX_F64(8, 1, 1, 2, 0)},
-#endif
 };
 
 }  // namespace

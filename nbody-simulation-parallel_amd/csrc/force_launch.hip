@@ -4,7 +4,11 @@
 // whose extra workgroups evaluate the close set -> scatter), all asynchronous on the caller's stream with no host read-back.
 #include "nbx_internal.h"
 
+#include <cxxabi.h>
+
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +38,13 @@ const Table& table() {
 }
 bool valid(int v) { return v >= 0 && v < (int)table().v.size(); }
 
+// the build of variant V that one force launch runs: Newtonian / softened / mixed-mode (spread sums) / plain
+void (*pick_kernel(const KernelVariant& V, int dim, int law, bool soft, bool qsum))(KArgs) {
+    return law ? ((dim == 3) ? V.newton3 : V.newton2)
+               : soft ? ((dim == 3) ? V.soft3 : V.soft2)
+               : (qsum && !V.aux) ? ((dim == 3) ? V.qs3 : V.qs2) : ((dim == 3) ? V.k3 : V.k2);
+}
+
 }  // namespace
 
 int num_variants() { return (int)table().v.size(); }
@@ -46,6 +57,21 @@ int variant_has_law_builds(int v) { return valid(v) && table().v[v].soft2 && tab
 int variant_planes(int v) { return valid(v) ? table().v[v].planes : 1; }
 int variant_has_qsum(int v) { return valid(v) && table().v[v].qs2 && table().v[v].qs3; }
 int variant_writes_aux(int v) { return valid(v) ? table().v[v].aux : 0; }
+int variant_has_clock_stamps(int v) { return valid(v) ? table().v[v].stamps : 0; }
+int variant_kernel_symbol(int v, int dim, int law, int soft, int qsum, char* buf, size_t len) {
+    if (!valid(v) || (dim != 2 && dim != 3) || !buf || len == 0) return -1;
+    void (*k)(KArgs) = pick_kernel(table().v[v], dim, law, soft != 0, qsum != 0);
+    if (!k) return -1;
+    // the name the code object was registered under (no device needed), demangled the way rocprofv3 prints it
+    const char* mangled = hipKernelNameRefByPtr(reinterpret_cast<const void*>(k), nullptr);
+    (void)hipGetLastError();
+    if (!mangled) return -1;
+    int status = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    std::snprintf(buf, len, "%s", (status == 0 && dem) ? dem : mangled);
+    std::free(dem);
+    return 0;
+}
 int default_fast_two_rcp_variant() { return table().def_two_rcp; }
 int variant_by_name(const char* name) {
     for (int i = 0; i < num_variants(); ++i)
@@ -80,6 +106,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.grid_slices = (int)slices;
     a.qsum = L.qsum;
     a.strict_list = nullptr; a.strict_acc = nullptr; a.strict_cap = 0; a.strict_slices = 0; a.strict_budget = 0; a.refine_c2 = 0.0;
+    a.clk = nullptr;
     a.cand_list = L.cand_list;
     a.cand_pos = L.cand_pos;
     a.bad_list = L.bad_list;
@@ -91,6 +118,7 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     a.n_total = (unsigned)L.n_total;
     a.shard_len = (unsigned)L.shard_len;
     a.eps2 = L.eps2;
+    a.clk = V.stamps ? L.clk : nullptr;
     const bool soft = L.eps2 > 0.0f;
     if (soft && !(V.fast && V.soft2 && V.soft3)) return hipErrorInvalidValue;   // softened law: fast kernels only
     if (L.law != 0 && !(soft && V.newton2 && V.newton3)) return hipErrorInvalidValue;   // Newtonian law: softened only
@@ -143,10 +171,12 @@ hipError_t launch_accel(int dim, const AccelLaunch& L, hipStream_t stream) {
     }
     if (L.lists_only) return hipSuccess;
     dim3 grid(L.pad / tgt_per_block + a.close_blocks, slices, 1);
+    if (a.clk) {   // close-set workgroups leave their slots zero: the reader skips them
+        if ((e = hipMemsetAsync(a.clk, 0, (size_t)grid.x * grid.y * 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if (L.clk_slots) *L.clk_slots = grid.x * grid.y;
+    }
     if (L.ev_start && (e = hipEventRecord(L.ev_start, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(L.law ? ((dim == 3) ? V.newton3 : V.newton2)
-                             : soft ? ((dim == 3) ? V.soft3 : V.soft2)
-                             : (L.qsum && !V.aux) ? ((dim == 3) ? V.qs3 : V.qs2) : ((dim == 3) ? V.k3 : V.k2), grid, block, 0, stream, a);
+    hipLaunchKernelGGL(pick_kernel(V, dim, L.law, soft, L.qsum != nullptr), grid, block, 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_stop && (e = hipEventRecord(L.ev_stop, stream)) != hipSuccess) return e;

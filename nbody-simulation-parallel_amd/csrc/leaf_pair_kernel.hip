@@ -37,6 +37,7 @@
 #include "../../include/nbody_hip.h"
 #include "nbx_ctx.h"
 #include "leaf_plan.h"
+#include "leaf_plan_device.h"
 
 #include <cmath>
 #include <cstdio>
@@ -340,10 +341,6 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
                 const float4* s = tile + 2u * g * T;
                 if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
                 else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
-#ifdef NBX_LEAF_EXPERIMENT_TWICE   /* timing experiment only: the pair work of every tile twice (wrong sums) */
-                if (safe) consume<D, LAW, false>(s, T, ix2, iy2, iz2, S);
-                else consume<D, LAW, true>(s, T, ix2, iy2, iz2, S);
-#endif
             }
         }
     }
@@ -381,7 +378,6 @@ struct LeafPackArgs {
     double* __restrict__ acc;
     const uint32_t* __restrict__ max_mass_bits;
 };
-constexpr int kPackMaxSubs = 16;                 // w >= 4
 
 #ifndef NBX_PACK_WAVES
 #define NBX_PACK_WAVES 4   /* waves per SIMD the register allocation aims at: 3D 110 VGPRs (5 spills 14 registers, 6 spills 34) */
@@ -728,7 +724,78 @@ void release_parked_leaf_arenas() {
 }
 }  // namespace nbx
 
+// ---- device-resident plan (include/nbody_hip.h "device-resident leaf plan") ---------------------------------------------------
+// What a tree code keeps between force evaluations while its tree stands: the validated structure laid out for the kernel
+// (leaf_plan.h) and every device buffer an evaluation needs.  An evaluation is then: gather (16 B per slot from the resident
+// fp32 source copy), pair kernel, and -- only if the caller wants them on the host -- forces by body and one copy out.
+struct nbx_leaf_plan {
+    int device = 0, dim = 3, waves = 2;
+    size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0, n_subs = 0, n_packs = 0;
+    char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass | packed leaves | packed waves
+    size_t arena_bytes = 0;         // what take_arena handed out (a parked block may be larger than asked for)
+    bool last_wait_ok = true;       // destroy: the wait for the last evaluation succeeded (else the block is freed, not parked)
+    float4* xp = nullptr;
+    double* sums = nullptr;         // [dim][pslots]
+    uint32_t* pslot_body = nullptr; // [pslots]
+    uint32_t* body_slot = nullptr;  // [n]  inverse map, 0xffffffff for a body in no leaf
+    CopyOp* ops = nullptr;
+    LeafBlock* blocks = nullptr;
+    uint32_t* max_mass = nullptr;
+    PackSub* subs = nullptr;
+    PackBlock* packs = nullptr;
+    double* forces = nullptr;       // [n][dim], allocated when a caller first asks for forces on the host
+    double* raw = nullptr;          // staged Body<D> array of nbx_leaf_plan_forces, allocated on first use
+    size_t raw_bytes = 0;
+    hipStream_t stream = nullptr;   // own stream (host-bodies path)
+    hipStream_t last_stream = nullptr;   // stream the last evaluation was ordered on
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
+    bool evaluated = false;
+    int last_law = NBX_LAW_TREE_LEAF;
+    double last_signedG = 0.0;
+    // masses of the last evaluation: a context's m64 (stride 1) or the staged bodies (offset 2 dim, stride the body's)
+    const double* last_mass = nullptr;
+    size_t last_mass_stride = 1;
+    bool forces_in_arena = false;   // `forces` is a piece of the arena (the one-shot call's plan), not an allocation of its own
+    bool device_planned = false;    // laid out on the device (leaf_plan_device.h); false: on the host (leaf_plan.h)
+    char* raw_arena = nullptr;      // one-shot call: the staged bodies come from the parked pool instead of hipMalloc
+    size_t raw_arena_bytes = 0;
+    nbx_leaf_dev::Summary summary_host;   // the device planner's 64 bytes land here
+};
+
 namespace {
+// The part of the validation that stays on the host whichever planner runs: the two offset arrays (n_leaves + 1 words each; the
+// lengths of every copy come from them).
+int validate_offsets(size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                     const uint32_t* list_sources, size_t* slots_out, size_t* n_list_out) {
+    if (n > ((size_t)1 << 31) || n_leaves > ((size_t)1 << 31)) return fail(NBX_ERR_INVALID, "too many bodies / leaves");
+    if (n_leaves && (!leaf_offsets || !list_offsets)) return fail(NBX_ERR_INVALID, "null leaf arrays");
+    const size_t slots = n_leaves ? leaf_offsets[n_leaves] : 0;
+    const size_t n_list = n_leaves ? list_offsets[n_leaves] : 0;
+    if (n_leaves && (leaf_offsets[0] != 0 || list_offsets[0] != 0)) return fail(NBX_ERR_INVALID, "CSR offsets must start at 0");
+    uint32_t bad = 0;                                    // no exit inside the loop: vectorised
+    for (size_t l = 0; l < n_leaves; ++l) bad |= (uint32_t)(leaf_offsets[l + 1] < leaf_offsets[l]) | (uint32_t)(list_offsets[l + 1] < list_offsets[l]);
+    if (bad) return fail(NBX_ERR_INVALID, "CSR offsets must be non-decreasing");
+    if ((slots && !leaf_bodies) || (n_list && !list_sources)) return fail(NBX_ERR_INVALID, "null leaf arrays");
+    *slots_out = slots;
+    *n_list_out = n_list;
+    return NBX_OK;
+}
+
+// Which planner lays a structure out.  NBODY_HIP_LEAF_PLANNER=host|device in the environment decides for every call (tests run
+// every case through both); otherwise the device takes structures from kDevicePlanFrom slots + list entries on -- below that the
+// host's few microseconds beat the device planner's ~35 launches.
+constexpr size_t kDevicePlanFrom = 65536;
+bool use_device_planner(size_t n_leaves, size_t slots, size_t n_list) {
+    if (n_leaves == 0 || slots == 0) return false;                                  // nothing to lay out: the host path's early exits
+    if (slots + n_leaves > 0xfffffff0ull || n_list > 0xfffffff0ull) return false;     // the host planner words the refusal
+    if (kPackWindowWaves * (size_t)kPackMaxSubs > 128) return false;                  // A/B builds with larger windows
+    if (const char* e = std::getenv("NBODY_HIP_LEAF_PLANNER")) {
+        if (!std::strcmp(e, "host")) return false;
+        if (!std::strcmp(e, "device")) return true;
+    }
+    return slots + n_list >= kDevicePlanFrom;
+}
+
 // Host-side validation of the CSR structure: every index the kernels will follow is checked here, before anything is launched.
 int validate_csr(size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
                  const uint32_t* list_sources, size_t* slots_out) {
@@ -772,6 +839,9 @@ int lay_out_launch(const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, si
     return fail(why == kPlanAllocFailed ? NBX_ERR_ALLOC : NBX_ERR_INVALID, why);
 }
 
+int create_plan(nbx_leaf_plan** out, int device, int dim, size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
+                const uint32_t* list_offsets, const uint32_t* list_sources, size_t forces_bytes);
+
 // The caller's current HIP device is put back when an entry point of this file returns
 struct DeviceScope {
     int before = -1;
@@ -791,7 +861,24 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     const size_t min_stride = (size_t)(2 * dim + 1) * sizeof(double);
     if (stride_bytes < min_stride || stride_bytes % sizeof(double) != 0)
         return fail(NBX_ERR_INVALID, "body stride must be a multiple of 8 and >= sizeof(Body<dim>)");
-    size_t slots = 0;
+    size_t slots = 0, n_list = 0;
+    if (int vrc = validate_offsets(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots, &n_list)) return vrc;
+    if (use_device_planner(n_leaves, slots, n_list)) {
+        // the structure laid out on the device (leaf_plan_device.h): a plan for this call alone, its block and the staged bodies' from the
+        // parked pool, so that a tree code calling once per step allocates nothing
+        nbx_leaf_plan* p = nullptr;
+        int prc = create_plan(&p, device, dim, n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, n * (size_t)dim * sizeof(double));
+        if (prc) return prc;
+        DeviceScope scope;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = take_arena(device, n * stride_bytes + 256, &p->raw_arena, &p->raw_arena_bytes);
+        if (e != hipSuccess) { prc = nbx::fail_hip(e, "staging the bodies", __FILE__, __LINE__); nbx_leaf_plan_destroy(p); return prc; }
+        p->raw = reinterpret_cast<double*>(p->raw_arena);
+        p->raw_bytes = n * stride_bytes;
+        prc = nbx_leaf_plan_forces(p, bodies, stride_bytes, law, G, forces_out, kernel_ms);
+        nbx_leaf_plan_destroy(p);
+        return prc;
+    }
     if (int vrc = validate_csr(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots)) return vrc;
     int ndev = 0;
     int rc = nbx_device_count(&ndev);
@@ -894,39 +981,6 @@ extern "C" int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_
     return NBX_OK;
 }
 
-// ---- device-resident plan (include/nbody_hip.h "device-resident leaf plan") ---------------------------------------------------
-// What a tree code keeps between force evaluations while its tree stands: the validated structure laid out for the kernel
-// (leaf_plan.h) and every device buffer an evaluation needs.  An evaluation is then: gather (16 B per slot from the resident
-// fp32 source copy), pair kernel, and -- only if the caller wants them on the host -- forces by body and one copy out.
-struct nbx_leaf_plan {
-    int device = 0, dim = 3, waves = 2;
-    size_t n = 0, pslots = 0, n_ops = 0, n_blocks = 0, n_subs = 0, n_packs = 0;
-    char* arena = nullptr;          // xp | sums | pslot_body | body_slot | ops | blocks | max_mass | packed leaves | packed waves
-    size_t arena_bytes = 0;         // what take_arena handed out (a parked block may be larger than asked for)
-    bool last_wait_ok = true;       // destroy: the wait for the last evaluation succeeded (else the block is freed, not parked)
-    float4* xp = nullptr;
-    double* sums = nullptr;         // [dim][pslots]
-    uint32_t* pslot_body = nullptr; // [pslots]
-    uint32_t* body_slot = nullptr;  // [n]  inverse map, 0xffffffff for a body in no leaf
-    CopyOp* ops = nullptr;
-    LeafBlock* blocks = nullptr;
-    uint32_t* max_mass = nullptr;
-    PackSub* subs = nullptr;
-    PackBlock* packs = nullptr;
-    double* forces = nullptr;       // [n][dim], allocated when a caller first asks for forces on the host
-    double* raw = nullptr;          // staged Body<D> array of nbx_leaf_plan_forces, allocated on first use
-    size_t raw_bytes = 0;
-    hipStream_t stream = nullptr;   // own stream (host-bodies path)
-    hipStream_t last_stream = nullptr;   // stream the last evaluation was ordered on
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr;
-    bool evaluated = false;
-    int last_law = NBX_LAW_TREE_LEAF;
-    double last_signedG = 0.0;
-    // masses of the last evaluation: a context's m64 (stride 1) or the staged bodies (offset 2 dim, stride the body's)
-    const double* last_mass = nullptr;
-    size_t last_mass_stride = 1;
-};
-
 namespace {
 
 int plan_set_device(const nbx_leaf_plan* p) {
@@ -978,49 +1032,59 @@ int plan_forces_out(nbx_leaf_plan* p, hipStream_t s, double* forces_out) {
     return NBX_OK;
 }
 
-}  // namespace
 
-extern "C" {
-
-int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies,
-                         size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources) {
-    if (!out) return fail(NBX_ERR_INVALID, "out is null");
-    *out = nullptr;
-    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
-    size_t slots = 0;
-    if (int vrc = validate_csr(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots)) return vrc;
-    int ndev = 0;
-    int rc = nbx_device_count(&ndev);
-    if (rc != NBX_OK) return rc;
-    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
-    LeafPlan host;
-    if (int prc = lay_out_launch(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host)) return prc;
-    nbx_leaf_plan* p = new (std::nothrow) nbx_leaf_plan();
-    if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
-    p->device = device; p->dim = dim; p->n = n; p->waves = host.waves;
-    p->pslots = host.pslots(); p->n_ops = host.ops.size(); p->n_blocks = host.blocks.size();
-    p->n_subs = host.pack_subs.size(); p->n_packs = host.pack_blocks.size();
-    std::vector<uint32_t> body_slot;
-    try { body_slot.assign(n, 0xffffffffu); } catch (...) { delete p; return fail(NBX_ERR_ALLOC, "host allocation failed"); }
-    for (size_t s = 0; s < p->pslots; ++s)
-        if (host.pslot_body[s] != 0xffffffffu) body_slot[host.pslot_body[s]] = (uint32_t)s;
-    DeviceScope scope;
 #define PLAN_TRY(expr)                                                                                             \
     do {                                                                                                           \
         hipError_t e_ = (expr);                                                                                    \
         if (e_ != hipSuccess) { const int r_ = nbx::fail_hip(e_, #expr, __FILE__, __LINE__); nbx_leaf_plan_destroy(p); return r_; } \
     } while (0)
-    PLAN_TRY(hipSetDevice(device));
-    PLAN_TRY(nbx::take_stream(device, &p->stream));
-    PLAN_TRY(hipEventCreate(&p->ev0));
-    PLAN_TRY(hipEventCreate(&p->ev1));
-    PLAN_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-    const size_t sizes[9] = {p->pslots * sizeof(float4), (size_t)dim * p->pslots * sizeof(double), p->pslots * sizeof(uint32_t),
-                             n * sizeof(uint32_t), p->n_ops * sizeof(CopyOp), p->n_blocks * sizeof(LeafBlock), sizeof(uint32_t),
-                             p->n_subs * sizeof(PackSub), p->n_packs * sizeof(PackBlock)};
-    size_t offs[9], total = 0;
-    for (int i = 0; i < 9; ++i) { offs[i] = total; total += (sizes[i] + 255) / 256 * 256 + 256; }
-    PLAN_TRY(take_arena(device, total, &p->arena, &p->arena_bytes));   // a tree code makes a plan per step: the last plan's block, parked by its destroy
+
+// The plan's buffers on the device, laid out there (leaf_plan_device.h): the four CSR arrays go over as they are, ~35 kernels build
+// what plan_leaves builds on the host, 64 bytes come back.  forces_bytes > 0 reserves the one-shot call's force array in the same block.
+int create_plan_on_device(nbx_leaf_plan* p, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                          const uint32_t* list_sources, size_t slots, size_t n_list, size_t forces_bytes) {
+    using namespace nbx_leaf_dev;
+    const Bounds b{p->n, n_leaves, slots, n_list};
+    const Layout L = make_layout(b, p->dim);
+    const size_t forces_off = L.total;
+    const size_t total = L.total + (forces_bytes ? (forces_bytes + 255) / 256 * 256 + 256 : 0);
+    PLAN_TRY(take_arena(p->device, total, &p->arena, &p->arena_bytes));
+    const DevicePlan d = plan_pointers(p->arena, L);
+    p->xp = d.xp; p->sums = d.sums; p->pslot_body = d.pslot_body; p->body_slot = d.body_slot; p->ops = d.ops; p->blocks = d.blocks;
+    p->subs = d.subs; p->packs = d.packs; p->max_mass = d.max_mass;
+    if (forces_bytes) { p->forces = reinterpret_cast<double*>(p->arena + forces_off); p->forces_in_arena = true; }
+    PLAN_TRY(enqueue_device_plan(b, p->dim, leaf_offsets, leaf_bodies, list_offsets, list_sources, NBX_LEAF_PACK != 0, p->arena, L, p->stream, &p->summary_host));
+    PLAN_TRY(hipStreamSynchronize(p->stream));
+    const Summary& S = p->summary_host;
+    if (S.err != kErrNone) {
+        const uint32_t code = S.err;
+        nbx_leaf_plan_destroy(p);
+        return fail(NBX_ERR_INVALID, error_text(code));
+    }
+    p->device_planned = true;
+    p->waves = (int)S.waves; p->pslots = S.pslots; p->n_ops = S.n_ops; p->n_blocks = S.n_blocks; p->n_subs = S.n_subs; p->n_packs = S.n_packs;
+    return NBX_OK;
+}
+
+int create_plan_on_host(nbx_leaf_plan* p, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves, const uint32_t* list_offsets,
+                        const uint32_t* list_sources, size_t forces_bytes) {
+    const size_t n = p->n;
+    const int dim = p->dim;
+    LeafPlan host;
+    if (int prc = lay_out_launch(leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, host)) { nbx_leaf_plan_destroy(p); return prc; }
+    p->waves = host.waves;
+    p->pslots = host.pslots(); p->n_ops = host.ops.size(); p->n_blocks = host.blocks.size();
+    p->n_subs = host.pack_subs.size(); p->n_packs = host.pack_blocks.size();
+    std::vector<uint32_t> body_slot;
+    try { body_slot.assign(n, 0xffffffffu); } catch (...) { nbx_leaf_plan_destroy(p); return fail(NBX_ERR_ALLOC, "host allocation failed"); }
+    for (size_t s = 0; s < p->pslots; ++s)
+        if (host.pslot_body[s] != 0xffffffffu) body_slot[host.pslot_body[s]] = (uint32_t)s;
+    const size_t sizes[10] = {(p->pslots + 2) * sizeof(float4), (size_t)dim * p->pslots * sizeof(double), p->pslots * sizeof(uint32_t),
+                              n * sizeof(uint32_t), p->n_ops * sizeof(CopyOp), p->n_blocks * sizeof(LeafBlock), sizeof(uint32_t),
+                              p->n_subs * sizeof(PackSub), p->n_packs * sizeof(PackBlock), forces_bytes};
+    size_t offs[10], total = 0;
+    for (int i = 0; i < 10; ++i) { offs[i] = total; total += (sizes[i] + 255) / 256 * 256 + 256; }
+    PLAN_TRY(take_arena(p->device, total, &p->arena, &p->arena_bytes));   // a tree code makes a plan per step: the last plan's block, parked by its destroy
     p->xp = reinterpret_cast<float4*>(p->arena + offs[0]);
     p->sums = reinterpret_cast<double*>(p->arena + offs[1]);
     p->pslot_body = reinterpret_cast<uint32_t*>(p->arena + offs[2]);
@@ -1030,6 +1094,7 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     p->max_mass = reinterpret_cast<uint32_t*>(p->arena + offs[6]);
     p->subs = reinterpret_cast<PackSub*>(p->arena + offs[7]);
     p->packs = reinterpret_cast<PackBlock*>(p->arena + offs[8]);
+    if (forces_bytes) { p->forces = reinterpret_cast<double*>(p->arena + offs[9]); p->forces_in_arena = true; }
     if (p->n_packs) {
         PLAN_TRY(hipMemcpyAsync(p->subs, host.pack_subs.data(), sizes[7], hipMemcpyHostToDevice, p->stream));
         PLAN_TRY(hipMemcpyAsync(p->packs, host.pack_blocks.data(), sizes[8], hipMemcpyHostToDevice, p->stream));
@@ -1038,16 +1103,59 @@ int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, con
     if (n) PLAN_TRY(hipMemcpyAsync(p->body_slot, body_slot.data(), sizes[3], hipMemcpyHostToDevice, p->stream));
     if (p->n_ops) PLAN_TRY(hipMemcpyAsync(p->ops, host.ops.data(), sizes[4], hipMemcpyHostToDevice, p->stream));
     if (p->n_blocks) PLAN_TRY(hipMemcpyAsync(p->blocks, host.blocks.data(), sizes[5], hipMemcpyHostToDevice, p->stream));
-    PLAN_TRY(hipMemsetAsync(p->sums, 0, sizes[1] ? sizes[1] : 8, p->stream));   // slots no workgroup writes (a leaf's pad) stay zero
-    if (p->pslots) {   // the pads of odd leaves: written here once (the body-major gather never touches them; the slot-major one rewrites them)
+    PLAN_TRY(hipStreamSynchronize(p->stream));   // the host arrays above go out of scope
+    return NBX_OK;
+}
+
+// nbx_leaf_plan_create and the one-shot call's plan: validation, the layout (device or host planner), the buffers an evaluation needs.
+int create_plan(nbx_leaf_plan** out, int device, int dim, size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
+                const uint32_t* list_offsets, const uint32_t* list_sources, size_t forces_bytes) {
+    if (!out) return fail(NBX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(NBX_ERR_INVALID, "dim must be 2 or 3");
+    size_t slots = 0, n_list = 0;
+    if (int vrc = validate_offsets(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots, &n_list)) return vrc;
+    const bool on_device = use_device_planner(n_leaves, slots, n_list);
+    if (!on_device)   // the host planner follows every index: all of them are checked first (the device planner checks as it goes)
+        if (int vrc = validate_csr(n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, &slots)) return vrc;
+    int ndev = 0;
+    int rc = nbx_device_count(&ndev);
+    if (rc != NBX_OK) return rc;
+    if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
+    nbx_leaf_plan* p = new (std::nothrow) nbx_leaf_plan();
+    if (!p) return fail(NBX_ERR_ALLOC, "host allocation failed");
+    p->device = device; p->dim = dim; p->n = n;
+    DeviceScope scope;
+    PLAN_TRY(hipSetDevice(device));
+    PLAN_TRY(nbx::take_stream(device, &p->stream));
+    PLAN_TRY(hipEventCreate(&p->ev0));
+    PLAN_TRY(hipEventCreate(&p->ev1));
+    PLAN_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    rc = on_device ? create_plan_on_device(p, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, slots, n_list, forces_bytes)
+                   : create_plan_on_host(p, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, forces_bytes);
+    if (rc) return rc;                                                    // p is gone already
+    // queued behind the layout, waited for by whoever evaluates first (plan_order_after_last): the sums of slots no workgroup
+    // writes (a leaf's pad) stay zero, and the pads of odd leaves are massless and far away (the body-major gather never touches them)
+    const size_t sum_bytes = (size_t)dim * p->pslots * sizeof(double);
+    PLAN_TRY(hipMemsetAsync(p->sums, 0, sum_bytes ? sum_bytes : 8, p->stream));
+    if (p->pslots) {
         hipLaunchKernelGGL(leaf_init_pads_kernel, dim3((unsigned)((p->pslots + 255) / 256)), dim3(256), 0, p->stream, p->pslot_body, (uint32_t)p->pslots,
                            dim, reinterpret_cast<float*>(p->xp));
         PLAN_TRY(hipGetLastError());
     }
-    PLAN_TRY(hipStreamSynchronize(p->stream));   // the host arrays above go out of scope
-#undef PLAN_TRY
+    if (int mrc = plan_mark_done(p, p->stream)) { nbx_leaf_plan_destroy(p); return mrc; }
     *out = p;
     return NBX_OK;
+}
+#undef PLAN_TRY
+
+}  // namespace
+
+extern "C" {
+
+int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n, const uint32_t* leaf_offsets, const uint32_t* leaf_bodies,
+                         size_t n_leaves, const uint32_t* list_offsets, const uint32_t* list_sources) {
+    return create_plan(out, device, dim, n, leaf_offsets, leaf_bodies, n_leaves, list_offsets, list_sources, 0);
 }
 
 int nbx_leaf_plan_destroy(nbx_leaf_plan* p) {
@@ -1059,8 +1167,9 @@ int nbx_leaf_plan_destroy(nbx_leaf_plan* p) {
     p->last_wait_ok = !(p->last_stream && p->done) || hipEventSynchronize(p->done) == hipSuccess;
     bool idle = p->stream && hipStreamSynchronize(p->stream) == hipSuccess;
     if (p->arena) { if (idle && p->last_wait_ok) park_arena(p->device, p->arena, p->arena_bytes); else (void)hipFree(p->arena); }
-    if (p->forces) (void)hipFree(p->forces);
-    if (p->raw) (void)hipFree(p->raw);
+    if (p->forces && !p->forces_in_arena) (void)hipFree(p->forces);
+    if (p->raw_arena) { if (idle && p->last_wait_ok) park_arena(p->device, p->raw_arena, p->raw_arena_bytes); else (void)hipFree(p->raw_arena); }
+    else if (p->raw) (void)hipFree(p->raw);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->done) (void)hipEventDestroy(p->done);

@@ -10,6 +10,12 @@
 #include <thread>
 #include <vector>
 
+#ifdef __HIPCC__
+#define NBX_LEAF_HD __host__ __device__
+#else
+#define NBX_LEAF_HD
+#endif
+
 namespace nbx_leaf {
 
 constexpr int kMaxWaves = 2;                   // wave64 per workgroup: each owns one piece of the leaf's targets, all stage the tiles
@@ -65,6 +71,18 @@ constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leav
 constexpr int kPackClasses = 5;                 // 1-2, 3-4, 5-6, 7-8, 9-16 bodies
 constexpr uint32_t kPackLanes[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, NBX_PACK_SIX_LANES, 8u, 16u};
 constexpr uint32_t kPackGroups[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, 2u, 2u};
+constexpr int kPackMaxSubs = 16;                // leaves to a wave at most: the packed kernel's LDS run tables and the layout's window keys are sized for it
+constexpr bool pack_classes_fit() {
+    for (int k = 0; k < kPackClasses; ++k) {
+        const uint32_t w = kPackLanes[k], P = kPackGroups[k];
+        const uint32_t max_c = k == 0 ? 2u : k == 1 ? 4u : k == 2 ? 6u : k == 3 ? 8u : 16u;   // largest leaf of the class
+        if (w < 1u || 64u / w > (uint32_t)kPackMaxSubs) return false;       // leaves to a wave
+        if (P < 1u || P * ((max_c + 1u) / 2u) > w) return false;            // every lane group's ceil(c / 2) lanes fit the leaf's w lanes
+    }
+    return true;
+}
+static_assert(pack_classes_fit(), "NBX_PACK_*_LANES: a class's lanes per leaf must hold its lane groups (P x ceil(c / 2) <= w) and give at most kPackMaxSubs leaves to a wave");
+static_assert(kPackClasses <= 8, "order_launch keeps one class per shape: kOrderShapes");
 constexpr int kPackPairsPerTrip = 2;            // the packed kernel computes two pairs while the next two are in flight
 struct PackSub {                               // one packed leaf
     uint32_t op_lo, op_n;                      // its copy runs
@@ -129,7 +147,7 @@ struct LeafPlan {
 // The order of a launch's workgroups.
 //  * Longest first: the launch ends when its last workgroup does, and workgroups are dispatched in index order -- with the
 //    short ones last the machine drains in a fraction of a mean workgroup's time (leaf order: 0.272 ms, sorted: 0.264 ms).
-//    A counting sort over 1024 duration classes, leaf order kept within a class.
+//    A counting sort over 1024 duration levels x 8 shapes, leaf order kept within a class.
 //  * One eighth of the structure per XCD: workgroup i runs on XCD i % 8 and every XCD has an L2 of its own, so with a class in
 //    plain leaf order every one of the eight L2s ends up fetching every body of the launch.  From kXcdOrderFrom workgroups on,
 //    the blocks of a duration class (in leaf order) are cut into eight runs, and run x takes the indices of the class that are
@@ -162,14 +180,21 @@ inline void run_threads(unsigned n, F f) {
     for (unsigned t = 1; t < started; ++t) helpers[t].join();
 }
 
-template <class Block, class Dur>
-inline void order_launch(std::vector<Block>& v, Dur dur) {
+// The sort key is lexicographic: (duration level, shape).  Durations are quantised into kOrderLevels levels of the longest one;
+// blocks of different SHAPES (the packed waves' size classes: equal trips are not equal durations) never share a class, whatever
+// the trip counts -- a class is dealt to the XCDs side by side, which was measured 40 % slower for mixed durations.
+constexpr uint32_t kOrderLevels = 1024, kOrderShapes = 8;
+NBX_LEAF_HD inline uint32_t order_class(uint32_t dur, uint32_t longest, uint32_t shape) {
+    return ((kOrderLevels - 1u) - (uint32_t)((uint64_t)dur * (kOrderLevels - 1u) / longest)) * kOrderShapes + shape;
+}
+template <class Block, class Dur, class Shape>
+inline void order_launch(std::vector<Block>& v, Dur dur, Shape shape) {
     const size_t n = v.size();
     if (n < 2) return;
     uint32_t longest = 1;
     for (const Block& b : v) if (dur(b) > longest) longest = dur(b);
-    constexpr uint32_t kClasses = 1024;
-    auto cls = [&](const Block& b) -> uint32_t { return (kClasses - 1u) - (uint32_t)((uint64_t)dur(b) * (kClasses - 1u) / longest); };
+    constexpr uint32_t kClasses = kOrderLevels * kOrderShapes;
+    auto cls = [&](const Block& b) -> uint32_t { return order_class(dur(b), longest, shape(b)); };
     std::vector<uint32_t> start(kClasses + 2, 0u);
     for (const Block& b : v) ++start[cls(b) + 2u];
     for (uint32_t k = 0; k <= kClasses; ++k) start[k + 1] += start[k];      // start[k + 1]: first index of class k
@@ -352,7 +377,7 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
             std::vector<uint32_t>& leaves_k = packable[k];
             const size_t i = (wi - win_base[k]) * kPackWindowWaves * per_wave;
             const size_t e = i + kPackWindowWaves * per_wave < leaves_k.size() ? i + kPackWindowWaves * per_wave : leaves_k.size();
-            uint64_t key[kPackWindowWaves * 16u];                          // longest first, leaf order among equals: one integer sort per window
+            uint64_t key[kPackWindowWaves * (size_t)kPackMaxSubs];                          // longest first, leaf order among equals: one integer sort per window
             for (size_t j = i; j < e; ++j) key[j - i] = ((uint64_t)(0xffffffffu - stream_units[leaves_k[j]]) << 32) | leaves_k[j];
             std::sort(key, key + (e - i));
             for (size_t j = i; j < e; ++j) leaves_k[j] = (uint32_t)key[j - i];
@@ -403,8 +428,8 @@ inline const char* plan_leaves(const uint32_t* leaf_offsets, const uint32_t* lea
     section(2);
     // waves of different shapes (lanes per leaf, lane groups) never share a duration class: equal trips are not equal durations, and
     // the blocks of a class are dealt to the XCDs side by side
-    order_launch(packs, [](const PackBlock& b) -> uint32_t { return (b.trips < (1u << 28) ? b.trips : (1u << 28)) * 8u + b.shape; });
-    order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; });
+    order_launch(packs, [](const PackBlock& b) -> uint32_t { return b.trips; }, [](const PackBlock& b) -> uint32_t { return b.shape; });
+    order_launch(blocks, [](const LeafBlock& b) -> uint32_t { return b.pad_[0]; }, [](const LeafBlock&) -> uint32_t { return 0u; });
     section(3);
 
     return nullptr;

@@ -5,6 +5,7 @@
 #include "nbx_internal.h"
 #include "nbx_ctx.h"
 
+#include <algorithm>
 #include <atomic>
 #include <climits>
 #include <cstdio>
@@ -352,10 +353,10 @@ int ensure_acc(nbx_ctx* c) {
             const unsigned cap = (unsigned)c->n_shards * c->pad;
             c->hash.capacity = cap;
             c->hash.temp_bytes = hash_temp_bytes(cap);
-            if ((rc = dev_alloc(c, &c->hash.keys, (size_t)cap * sizeof(unsigned long long)))) return rc;
-            if ((rc = dev_alloc(c, &c->hash.keys_sorted, (size_t)cap * sizeof(unsigned long long)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.keys, (size_t)cap * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.keys_alt, (size_t)cap * sizeof(unsigned)))) return rc;
             if ((rc = dev_alloc(c, &c->hash.vals, (size_t)cap * sizeof(unsigned)))) return rc;
-            if ((rc = dev_alloc(c, &c->hash.vals_sorted, (size_t)cap * sizeof(unsigned)))) return rc;
+            if ((rc = dev_alloc(c, &c->hash.vals_alt, (size_t)cap * sizeof(unsigned)))) return rc;
             char* temp = nullptr;
             if ((rc = dev_alloc(c, &temp, c->hash.temp_bytes))) return rc;
             c->hash.temp = temp;
@@ -862,6 +863,56 @@ int nbx_ctx_effective_tuning(nbx_ctx* c, int* variant, int* source_splits) {
     return NBX_OK;
 }
 
+int nbx_variant_kernel_symbol(int variant, int dim, int mixed_mode, char* buf, size_t len) {
+    if (!buf || len < 16 || (dim != 2 && dim != 3) || variant < 0 || variant >= num_variants()) return fail(NBX_ERR_INVALID, "bad argument");
+    if (mixed_mode && !(variant_is_fast(variant) && variant_has_qsum(variant))) return fail(NBX_ERR_INVALID, "the variant has no mixed-mode build");
+    if (variant_kernel_symbol(variant, dim, 0, 0, mixed_mode || variant_writes_aux(variant), buf, len))
+        return fail(NBX_ERR_STATE, "the kernel's symbol is not known to the runtime");
+    return NBX_OK;
+}
+
+int nbx_ctx_enable_clock_stamps(nbx_ctx* c, int on) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (on && !c->clk) {
+        const int v = effective_variant(c);
+        if (!variant_has_clock_stamps(v)) return fail(NBX_ERR_STATE, "the force kernel that would run carries no clock stamps (three-level variants only)");
+        // room for the largest grid this variant launches on this shard: target blocks + close-set blocks, times the slices
+        const size_t cap = ((size_t)c->pad / (256u * (unsigned)variant_tpl(v)) + (size_t)kCloseBlocksX) * (size_t)(kMaxSplits / variant_planes(v));
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, cap * 2 * sizeof(unsigned long long)));
+        c->extra.push_back(p);
+        c->clk = static_cast<unsigned long long*>(p);
+        c->clk_cap = cap;
+    }
+    c->clk_on = on != 0;
+    c->clk_slots = 0;
+    return NBX_OK;
+}
+
+int nbx_ctx_shader_clock(nbx_ctx* c, double* median_mhz, double* min_mhz, double* max_mhz, int* workgroups) {
+    if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
+    if (!c->clk || !c->clk_slots) return fail(NBX_ERR_STATE, "no stamped force launch yet (nbx_ctx_enable_clock_stamps, then an evaluation)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> h;
+    try { h.resize((size_t)c->clk_slots * 2); } catch (...) { return fail(NBX_ERR_ALLOC, "host staging allocation failed"); }
+    HIP_TRY(hipMemcpy(h.data(), c->clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (unsigned i = 0; i < c->clk_slots; ++i)
+        if (h[2 * i + 1] >= 1000) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);   // >= 10 us of work: close-set and empty workgroups drop out
+    if (mhz.empty()) return fail(NBX_ERR_STATE, "the stamped launch had no workgroup long enough to read a clock from");
+    std::sort(mhz.begin(), mhz.end());
+    if (median_mhz) *median_mhz = mhz[mhz.size() / 2];
+    if (min_mhz) *min_mhz = mhz.front();
+    if (max_mhz) *max_mhz = mhz.back();
+    if (workgroups) *workgroups = (int)mhz.size();
+    return NBX_OK;
+}
+
 int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     if (!c) return fail(NBX_ERR_INVALID, "ctx is null");
     if (!c->uploaded) return fail(NBX_ERR_STATE, "upload bodies before computing accelerations");
@@ -882,6 +933,10 @@ int nbx_ctx_compute_accel(nbx_ctx* c, int which) {
     L.law = c->law;
     L.lists_only = 0;
     const bool refine = refine_active(c, c->variant);
+    if (c->clk_on && c->clk && variant_has_clock_stamps(c->variant) &&
+        ((size_t)c->pad / (256u * (unsigned)variant_tpl(c->variant)) + (size_t)kCloseBlocksX) * (size_t)(c->splits / variant_planes(c->variant)) <= c->clk_cap) {
+        L.clk = c->clk; L.clk_slots = &c->clk_slots;
+    }
     L.qsum = (refine || variant_writes_aux(c->variant)) ? c->qsum : nullptr;
     if (c->hash_refine && variant_is_fast(c->variant) && !(c->softening > 0.0)) L.hash = c->hash;
     if (c->law != 0 && !(c->softening > 0.0)) return fail(NBX_ERR_STATE, "the Newtonian law needs a softening length (nbx_ctx_set_softening)");
@@ -967,7 +1022,7 @@ int nbx_ctx_kick_drift(nbx_ctx* c, double G, double dt) { return nbx_ctx_kick_dr
 static bool capture_step(nbx_ctx* c, double G, double dt) {
     if (c->step_exec && c->graph_G == G && c->graph_dt == dt && c->graph_variant == c->variant &&
         c->graph_splits == c->splits && c->graph_stream == c->stream && c->graph_eps == c->softening && c->graph_law == c->law && c->graph_hash == c->hash_refine &&
-        c->graph_refine_tol == c->refine_tol && c->graph_refine_sigma == c->refine_sigma)
+        c->graph_refine_tol == c->refine_tol && c->graph_refine_sigma == c->refine_sigma && c->graph_clk == (c->clk_on ? c->clk : nullptr))
         return true;
     if (c->step_exec) { (void)hipGraphExecDestroy(c->step_exec); c->step_exec = nullptr; }
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -984,6 +1039,7 @@ static bool capture_step(nbx_ctx* c, double G, double dt) {
     if (ei != hipSuccess) { c->step_exec = nullptr; (void)hipGetLastError(); return false; }
     c->graph_eps = c->softening; c->graph_law = c->law; c->graph_hash = c->hash_refine;
     c->graph_refine_tol = c->refine_tol; c->graph_refine_sigma = c->refine_sigma;
+    c->graph_clk = c->clk_on ? c->clk : nullptr;
     c->graph_G = G; c->graph_dt = dt; c->graph_variant = c->variant; c->graph_splits = c->splits; c->graph_stream = c->stream;
     return true;
 }

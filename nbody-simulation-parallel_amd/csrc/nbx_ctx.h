@@ -96,6 +96,12 @@ struct nbx_ctx {
     double last_refine_ms_total = 0.0;  // mixed-mode time of the evaluations the last nbx_ctx_kernel_time call covered
     int ev_used = 0;
     int launches_since_query = 0;
+    // measurement: in-kernel clock stamps of the force kernel (nbx_ctx_enable_clock_stamps / nbx_ctx_shader_clock)
+    bool clk_on = false;
+    unsigned long long* clk = nullptr;   // [2 x clk_cap], its own allocation
+    size_t clk_cap = 0;                  // workgroups it has room for
+    unsigned clk_slots = 0;              // workgroups of the last stamped launch
+    unsigned long long* graph_clk = nullptr;   // the stamp buffer baked into the captured step (null: none)
     int num_cus = 256;
 };
 

@@ -59,13 +59,13 @@ constexpr int kCloseBlocksX = 32;          // extra workgroups per source slice 
 
 // Workspace of the sorted-cell form of the close-set refinement (close_hash.hip); all null when not in use.
 struct HashWork {
-    unsigned long long* keys = nullptr;         // [capacity] cell keys of the pass's candidate sources (~0: empty slot)
-    unsigned long long* keys_sorted = nullptr;
-    unsigned* vals = nullptr;                   // [capacity] slot in src_cand_pos
-    unsigned* vals_sorted = nullptr;
-    void* temp = nullptr;                       // hipcub radix-sort scratch
+    unsigned* keys = nullptr;          // [capacity] 32-bit cell keys of the pass's candidate sources; sorted in place (four passes, two buffers)
+    unsigned* keys_alt = nullptr;      // [capacity] the radix sort's second buffer
+    unsigned* vals = nullptr;          // [capacity] slot in src_cand_pos, carried along
+    unsigned* vals_alt = nullptr;
+    void* temp = nullptr;              // per-tile digit histograms of the radix sort
     size_t temp_bytes = 0;
-    unsigned capacity = 0;                      // = n_chunks * pad (every body may be a candidate)
+    unsigned capacity = 0;             // = n_chunks * pad (every body may be a candidate)
 };
 
 // How one force evaluation walks the exchange buffer  pos_all[n_shards][dim][pad] / mass_all[n_shards][pad].
@@ -106,6 +106,10 @@ struct AccelLaunch {
     float* qsum = nullptr;
     // optional: recorded on the stream immediately before / after the main force kernel
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // measurement (nbx_ctx_enable_clock_stamps): non-null = every workgroup of the three-level force kernel stamps the shader
+    // clock and the 100 MHz reference clock around its work -- [2 x workgroups of the launch] {d s_memtime, d s_memrealtime}
+    unsigned long long* clk = nullptr;
+    unsigned* clk_slots = nullptr;   // host: receives the number of workgroups of the stamped launch
 };
 
 // Kernel-side view of one force launch (built by launch_accel from an AccelLaunch).
@@ -141,6 +145,7 @@ struct KArgs {
     int strict_slices;                 // most source slices the fp64 pass may use (<= 256, <= total_tiles) = its gridDim.y
     unsigned long long strict_budget;  // doubles in strict_acc: slices x dim x stride never exceeds it
     double refine_c2;                  // a target is listed when |a|^2 < refine_c2 * Q  (Q = sum over slices of qsum)
+    unsigned long long* __restrict__ clk;   // null, or [2 x gridDim.x x gridDim.y] clock stamps (AccelLaunch::clk)
 };
 
 struct KernelVariant {
@@ -159,6 +164,7 @@ struct KernelVariant {
     void (*qs3)(KArgs);
     int planes;              // fp32 planes of acc written per source slice: 1, or 2 = {hi, lo} of an fp64 sum (strict kernel)
     int aux;                 // 1: the kernel itself writes KArgs::qsum (the strict kernel's magnitude-sum build)
+    int stamps;              // 1: the kernel writes KArgs::clk when it is non-null (measurement)
 };
 // force_kernel.hip
 const KernelVariant* kernel_variants(int* count);
@@ -200,6 +206,9 @@ int variant_has_law_builds(int variant);  // softened / Newtonian builds of the 
 int variant_planes(int variant);          // fp32 planes of acc per source slice (2: strict fp64 kernel)
 int variant_has_qsum(int variant);        // the variant has a build that writes qsum (mixed mode possible)
 int variant_writes_aux(int variant);      // the variant's own kernel writes qsum (strict magnitude-sum build)
+int variant_has_clock_stamps(int variant);   // the variant's kernel honours AccelLaunch::clk (the three-level kernel)
+// demangled symbol of the kernel launch_accel launches for (variant, dim, law, softened, mixed mode) -- the name rocprofv3 prints
+int variant_kernel_symbol(int variant, int dim, int law, int soft, int qsum, char* buf, size_t len);
 int default_fast_two_rcp_variant();   // fast variant without the extent precondition
 int variant_by_name(const char* name);
 int default_variant();        // the fast default

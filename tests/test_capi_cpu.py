@@ -28,7 +28,7 @@ def test_library_exports_every_symbol(nbx):
     lib = ctypes.CDLL(nbx.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/nbody_hip.h but not exported"
-    assert nbx.load_library().nbx_abi_version() == 4
+    assert nbx.load_library().nbx_abi_version() == 5
 
 
 def test_library_exports_nothing_but_the_header(nbx):

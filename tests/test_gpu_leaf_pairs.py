@@ -342,7 +342,7 @@ def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
 def test_plan_stepping_matches_the_reference_helpers(nbx, oracle):
     """nbx_leaf_plan_kick_drift: update_body_velocities + update_body_positions (methods.cpp:425-450) fed the leaf sums of a
     standing structure, k steps on the device, against the same loop on the host built from the oracle's leaf sums on the
-    fp32-representable positions the device sees.  Strong coupling (G x 1e24) so that the forces bend the paths; bodies in no
+    fp32-representable positions the device sees.  Strong coupling (G x 1e26) so that the forces bend the paths; bodies in no
     leaf only drift.  Per-body bound from the stated force tolerance, as in test_config2_trajectory_with_coupling."""
     n, dim, steps, dt, scale = 8000, 3, 4, 1.5, 1e26
     b0 = oracle.round_inputs_to_f32(oracle.generate(150, n, dim))
