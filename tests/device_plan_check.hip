@@ -2,7 +2,7 @@
 // caller's CSR arrays from raw uint32 files <dir>/{leaf_offsets,leaf_bodies,list_offsets,list_sources}.u32, lays the launch out on
 // the host (csrc/leaf_plan.h plan_leaves) and on the device (enqueue_device_plan), and compares every array of the two plans word
 // for word.  Prints "identical ..." and returns 0, or says where they differ.  With a second argument N it also times N device
-// layouts (stream time between two events, copies included).
+// layouts (stream time between two events, copies included); with "refuse" only the device planner runs and its verdict is printed.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -48,7 +48,8 @@ int main(int argc, char** argv) {
     if (argc < 2) return 2;
     using namespace nbx_leaf_dev;
     const std::string d = std::string(argv[1]) + "/";
-    const int reps = argc > 2 ? atoi(argv[2]) : 0;
+    const bool device_only = argc > 2 && !strcmp(argv[2], "refuse");   // a structure the host planner must not be shown (it follows every index unchecked)
+    const int reps = argc > 2 && !device_only ? atoi(argv[2]) : 0;
     const std::vector<uint32_t> lo = load(d + "leaf_offsets.u32"), lb = load(d + "leaf_bodies.u32"), so = load(d + "list_offsets.u32"),
                                 ss = load(d + "list_sources.u32");
     const size_t n_leaves = lo.size() - 1;
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
     for (uint32_t b : lb) n = b + 1 > n ? b + 1 : n;
     if (FILE* f = fopen((d + "n_bodies.txt").c_str(), "r")) { unsigned v = 0; if (fscanf(f, "%u", &v) == 1) n = v; fclose(f); }
     nbx_leaf::LeafPlan host;
-    const char* why = nbx_leaf::plan_leaves(lo.data(), lb.data(), n_leaves, so.data(), ss.data(), host);
+    const char* why = device_only ? nullptr : nbx_leaf::plan_leaves(lo.data(), lb.data(), n_leaves, so.data(), ss.data(), host);
     Bounds b{n, n_leaves, lo[n_leaves], so[n_leaves]};
     const Layout L = make_layout(b, 3);
     char* arena = nullptr;
@@ -66,6 +67,10 @@ int main(int argc, char** argv) {
     Summary sum{};
     CK(enqueue_device_plan(b, 3, lo.data(), lb.data(), so.data(), ss.data(), true, arena, L, s, &sum));
     CK(hipStreamSynchronize(s));
+    if (device_only) {
+        printf("device: %s\n", sum.err != kErrNone ? error_text(sum.err) : "accepted");
+        return 0;
+    }
     if (why || sum.err != kErrNone) {
         printf("host: %s; device: %s\n", why ? why : "accepted", sum.err != kErrNone ? error_text(sum.err) : "accepted");
         return (why != nullptr) == (sum.err != kErrNone) ? 0 : 1;

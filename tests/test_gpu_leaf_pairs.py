@@ -12,20 +12,45 @@ pytestmark = pytest.mark.gpu
 LAWS = ((0, "brute"), (1, "tree_leaf"), (2, "fmm_p2p"))
 
 
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def planner(which):
+    """NBODY_HIP_LEAF_PLANNER=host|device: which planner lays the structure out (csrc/leaf_plan.h on the host, csrc/leaf_plan_device.h
+    on the device); the library reads it on every call.  Unset, the size of the structure decides."""
+    before = os.environ.get("NBODY_HIP_LEAF_PLANNER")
+    os.environ["NBODY_HIP_LEAF_PLANNER"] = which
+    try:
+        yield
+    finally:
+        if before is None:
+            del os.environ["NBODY_HIP_LEAF_PLANNER"]
+        else:
+            os.environ["NBODY_HIP_LEAF_PLANNER"] = before
+
+
 def _all_paths(nbx, b, leaves, law, G, what=""):
     """The three ways into the pair kernel give the same bits: the one-shot call (nbx_leaf_pair_forces: validates, lays out and
     uploads per call), the resident PLAN fed host bodies (nbx_leaf_plan_forces), and the plan fed bodies that live in a context
-    (nbx_leaf_plan_forces_ctx) -- twice, the second time with the sums left on the device (nbx_leaf_plan_get_forces)."""
-    f = nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=G)
+    (nbx_leaf_plan_forces_ctx) -- twice, the second time with the sums left on the device (nbx_leaf_plan_get_forces).  All of it
+    through BOTH planners: the structure laid out on the host and on the device must give the same bits too."""
     n, dim = b.shape[0], (b.shape[1] - 1) // 2
-    with nbx.LeafPlan(n, dim, *leaves) as plan:
-        assert np.array_equal(plan.forces(b, law, G), f), f"{what}: plan (host bodies) differs from the one-shot call"
-        if n:
-            with nbx.Context(n, dim) as c:
-                c.upload(b)
-                assert np.array_equal(plan.forces_ctx(c, law, G), f), f"{what}: plan (resident bodies) differs from the one-shot call"
-                plan.forces_ctx(c, law, G, fetch=False)
-                assert np.array_equal(plan.get_forces(), f), f"{what}: second evaluation of the unchanged structure"
+    with planner("host"):
+        f = nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=G)
+    for which in ("host", "device"):
+        with planner(which):
+            if which == "device":
+                assert np.array_equal(nbx.leaf_pair_forces_hip(b, *leaves, law=law, G=G), f), f"{what}: one-shot call, device planner, differs from the host planner's"
+            with nbx.LeafPlan(n, dim, *leaves) as plan:
+                assert np.array_equal(plan.forces(b, law, G), f), f"{what}: plan (host bodies, {which} planner) differs from the one-shot call"
+                if n:
+                    with nbx.Context(n, dim) as c:
+                        c.upload(b)
+                        assert np.array_equal(plan.forces_ctx(c, law, G), f), f"{what}: plan (resident bodies, {which} planner) differs from the one-shot call"
+                        plan.forces_ctx(c, law, G, fetch=False)
+                        assert np.array_equal(plan.get_forces(), f), f"{what}: second evaluation of the unchanged structure ({which} planner)"
     return f
 
 
@@ -281,10 +306,13 @@ def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
         (np.array([1, 5, 10]), np.arange(10), np.array([0, 1, 2]), np.array([0, 1])),      # offsets not starting at 0
     ]
     for leaves in bad:
-        with pytest.raises(nbx.NbxError):
-            nbx.leaf_pair_forces_hip(b, *leaves)
-        with pytest.raises(nbx.NbxError):
-            nbx.LeafPlan(10, 3, *leaves)
+        for which in ("host", "device"):     # the device planner checks the indices as it follows them; nothing out of range is ever dereferenced
+            with planner(which):
+                with pytest.raises(nbx.NbxError):
+                    nbx.leaf_pair_forces_hip(b, *leaves)
+                with pytest.raises(nbx.NbxError):
+                    nbx.LeafPlan(10, 3, *leaves)
+                nbx.leaf_pair_forces_hip(b, *ok)        # and the next good call is served
     with pytest.raises(nbx.NbxError):
         nbx.leaf_pair_forces_hip(b, *ok, law=7)
     with nbx.LeafPlan(10, 3, *ok) as plan:
