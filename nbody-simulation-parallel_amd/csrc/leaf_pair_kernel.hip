@@ -251,16 +251,24 @@ __device__ __forceinline__ void consume(const float4* __restrict__ s, const unsi
 //    multiples of 32 B, which no two of <= 8 groups share a bank on.  Pairs past the tile's end are the pad pairs.
 //  * A body meets itself in its own leaf: r^2 = 0 falls under every law's skip rule (methods.cpp:113 skips i == j by
 //    index, which only differs from the r^2 rule for r^2 >= 1e-10 -- impossible for a body and itself).
+// LDS of one one-leaf workgroup: the tile (+ what the pipelined pair loop reads ahead of its last trip), the run tables, the closing sums
+template <int WAVES>
+constexpr unsigned pair_smem_bytes() {
+    return (unsigned)((64 * WAVES * kUnitsPerLane + 2 * kPadPairs + 16) * sizeof(float4) + 2 * kMaxOps * sizeof(uint32_t) + 3 * 64 * WAVES * sizeof(double));
+}
 template <int D, int LAW, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
+__device__ __forceinline__ void leaf_pair_body(const LeafArgs& a, const unsigned block, char* __restrict__ smem) {
     constexpr int kThreads = 64 * WAVES;
     constexpr int kTileUnits = kThreads * kUnitsPerLane;
-    __shared__ float4 tile[kTileUnits + 2 * kPadPairs + 16];   // + what the pipelined pair loop reads ahead of its last trip
-    __shared__ uint32_t op_end[kMaxOps], op_base[kMaxOps];
+    constexpr int kTileSlots = kTileUnits + 2 * kPadPairs + 16;
+    float4* const tile = reinterpret_cast<float4*>(smem);
+    uint32_t* const op_end = reinterpret_cast<uint32_t*>(smem + kTileSlots * sizeof(float4));
+    uint32_t* const op_base = op_end + kMaxOps;
+    double (*const osum)[kThreads] = reinterpret_cast<double (*)[kThreads]>(smem + kTileSlots * sizeof(float4) + 2 * kMaxOps * sizeof(uint32_t));
     static_assert(kUnitsPerLane == 2 || kUnitsPerLane == 4, "the kernel names two or four staging registers");
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const LeafBlock* __restrict__ bp = a.blocks + blockIdx.x;
+    const LeafBlock* __restrict__ bp = a.blocks + block;
     const uint32_t op_lo = bp->op_lo, op_n = bp->op_n;
     const uint32_t max_mass_bits = *a.max_mass_bits;
     const uint32_t p_first = bp->piece[wave].first, p_count = bp->piece[wave].count;
@@ -284,7 +292,6 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
     const bool in_close_set = !(__builtin_fabsf(ix) >= kCloseCoord && __builtin_fabsf(iy) >= kCloseCoord && (D == 2 || __builtin_fabsf(iz) >= kCloseCoord));
     const bool safe = __builtin_amdgcn_ballot_w64(in_close_set) == 0ull && max_mass_bits <= __builtin_bit_cast(uint32_t, (float)kFastMaxMass);
     Sums<D> S;
-    __shared__ double osum[3][kThreads];
     osum[0][tid] = 0.0; osum[1][tid] = 0.0; osum[2][tid] = 0.0;   // only this lane touches them until the closing barrier
     S.o = &osum[0][tid];
     S.stride = (unsigned)kThreads;
@@ -357,6 +364,12 @@ __global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
     }
 }
 
+template <int D, int LAW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void leaf_pair_kernel(LeafArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[pair_smem_bytes<WAVES>()];
+    leaf_pair_body<D, LAW, WAVES>(a, blockIdx.x, smem);
+}
+
 // Packed small leaves (leaf_plan.h PackBlock): one wave64 = K = 64 / w leaves side by side, P lanes per target.  Nothing is staged:
 // lane group g of a target walks pairs [g T, (g + 1) T) of its leaf's source stream straight from memory (two 16-byte loads per
 // pair; the lanes of a leaf's targets share addresses, so a wave's load touches K x P distinct 32-byte records -- L2 hits, the
@@ -382,12 +395,29 @@ struct LeafPackArgs {
 #ifndef NBX_PACK_WAVES
 #define NBX_PACK_WAVES 4   /* waves per SIMD the register allocation aims at: 3D 110 VGPRs (5 spills 14 registers, 6 spills 34) */
 #endif
+// Round 5: the pair OFFSETS of the wave's leaves are expanded into LDS once, before the loop -- entry q of a leaf's row is the byte
+// offset of pair q of its stream (the pad pair's behind the stream's end) -- so that the loop reads two offsets with one ds_read_b64
+// (one stage ahead of the loads they address) where it used to step a cursor through the copy runs for every pair: ~16 VALU per
+// loop body of 52 (profiles/r4/pmc_pack_kernel.txt: 39 % of the wave's instructions were bookkeeping).  Waves whose rows do not
+// fit kPackExpand entries (K x P x T; long streams) keep the cursor loop.
+#ifndef NBX_PACK_EXPAND
+#define NBX_PACK_EXPAND 1280
+#endif
+constexpr unsigned kPackExpand = NBX_PACK_EXPAND;           // offsets per wave: 5 KB; with the run tables 9.3 KB of LDS per wave, 17 waves per CU
+constexpr unsigned kPackExpandSlack = 8;         // the pipelined loop reads offsets up to 6 entries past its share
+constexpr unsigned kPackTableWords = 2u * kPackMaxSubs * (kPackMaxOps + 1);
+constexpr unsigned kPackSmemBytes = (kPackTableWords + kPackExpand + kPackExpandSlack) * 4u;
 template <int D, int LAW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAVES, 8))) void leaf_pack_kernel(LeafPackArgs a) {
-    __shared__ uint32_t op_end[kPackMaxSubs][kPackMaxOps + 1], op_base[kPackMaxSubs][kPackMaxOps + 1];   // + the pad run behind a leaf's last
-    __shared__ double osum[3][128];                                // [component][second target? 64 : 0][lane]
+__device__ __forceinline__ void leaf_pack_body(const LeafPackArgs& a, const unsigned block, char* __restrict__ smem) {
+    constexpr unsigned kTableWords = kPackTableWords;
+    static_assert(kTableWords * 4u >= 3u * 128u * sizeof(double) && (kPackExpand + kPackExpandSlack) * 4u >= 3u * 128u * sizeof(double), "either region can hold the closing sums");
+    static_assert(kTableWords % 4u == 0u, "the offsets behind the tables are read as 8-byte pairs");
+    uint32_t* const tables = reinterpret_cast<uint32_t*>(smem);                 // the leaves' copy runs; the expanded path's closing sums afterwards
+    uint32_t* const poff = tables + kTableWords;                                // expanded pair offsets; the cursor path's closing sums
+    uint32_t (*op_end)[kPackMaxOps + 1] = reinterpret_cast<uint32_t (*)[kPackMaxOps + 1]>(tables);
+    uint32_t (*op_base)[kPackMaxOps + 1] = reinterpret_cast<uint32_t (*)[kPackMaxOps + 1]>(tables + kPackMaxSubs * (kPackMaxOps + 1));
     const unsigned lane = threadIdx.x;
-    const PackBlock* __restrict__ bp = a.blocks + blockIdx.x;
+    const PackBlock* __restrict__ bp = a.blocks + block;
     const uint32_t w = bp->w, inv_w = bp->inv_w, P = bp->P, n_sub = bp->n_sub, sub_lo = bp->sub_lo, T = bp->trips;   // wave-uniform
     const unsigned sub = (lane * inv_w) >> 16, lw = lane - sub * w;   // w is 4, 6, 8 or 16: 64 / w leaves; the lanes left over (w = 6: four) hold no leaf
     PackSub my = PackSub{0u, 0u, 0u, 0u};
@@ -414,23 +444,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
     // this leaf's copy runs, as {end of the run in the stream, byte offset of the run's first unit minus 16 x its stream position}
     // (32-bit byte offsets from a scalar base: the plan packs nothing beyond 2^28 units), and behind the last one the PAD RUN:
     // it never ends, and every position of it is the launch's pad pair (its positions are masked to zero)
-    for (unsigned k = lw; k < my.op_n; k += w) {
-        const CopyOp o = a.ops[my.op_lo + k];
-        op_end[sub][k] = o.end;
-        op_base[sub][k] = o.base << 4;
+    const uint32_t PT = P * T;                                     // entries of a leaf's row = pairs its lane groups walk between them
+    const bool expanded = T != 0u && n_sub * PT <= kPackExpand;    // wave-uniform
+    if (!expanded) {                                               // the cursor loop's run tables
+        for (unsigned k = lw; k < my.op_n; k += w) {
+            const CopyOp o = a.ops[my.op_lo + k];
+            op_end[sub][k] = o.end;
+            op_base[sub][k] = o.base << 4;
+        }
+        if (lw == 0u) { op_end[sub][my.op_n] = 0xffffffffu; op_base[sub][my.op_n] = a.pslots << 4; }
     }
-    if (lw == 0u) { op_end[sub][my.op_n] = 0xffffffffu; op_base[sub][my.op_n] = a.pslots << 4; }
     Sums<D> S0, S1;
     bool flushed = false;                                          // wave-uniform: the fp64 sums hold something (they are not zeroed: the first flush stores)
-    S0.o = &osum[0][lane];
-    S1.o = &osum[0][64u + lane];
+    double* const osum = reinterpret_cast<double*>(expanded ? tables : poff);   // [component][second target? 64 : 0][lane], in the region the loop does not use
+    S0.o = osum + lane;
+    S1.o = osum + 64u + lane;
     S0.stride = S1.stride = 128u;
-    __syncthreads();                                               // the run tables (one wave: cheap)
-    // Lane group g walks stream positions [2 g T, 2 (g + 1) T) of its leaf.  The cursor k only ever moves forward; the run it is in
-    // sits in registers.  A lane without a target starts (and stays) in a pad run of its own.
-    const uint32_t v_begin = 2u * g * T;
+    if (!expanded) __syncthreads();                                // the run tables (one wave: cheap)
+    // The cursor k only ever moves forward; the run it is in sits in registers.  A lane without a leaf starts (and stays) in a pad
+    // run of its own.
     unsigned k = 0;
-    uint32_t run_end = valid ? 0u : 0xffffffffu, run_off = a.pslots << 4, run_mask = 0u;
+    uint32_t run_end = my.count ? 0u : 0xffffffffu, run_off = a.pslots << 4, run_mask = 0u;
     auto offset_of = [&](const uint32_t v) -> uint32_t {           // byte offset of the pair at stream position v (even)
         while (v >= run_end) {                                     // rare (a run is ~3 leaves); the pad run ends the search
             run_end = op_end[sub][k];
@@ -440,51 +474,135 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         }
         return ((v & run_mask) << 4) + run_off;                    // a run is whole leaves, a leaf whole pairs: both units of the pair
     };
-    auto issue = [&](const uint32_t i, float4 (&A)[2], float4 (&B)[2]) {   // pairs i and i + 1 of this lane's share
-        const uint32_t v = v_begin + 2u * i;
-        const uint32_t o0 = offset_of(v), o1 = offset_of(v + 2u);
-        const float4* __restrict__ s0 = reinterpret_cast<const float4*>(xp_bytes + o0);
-        const float4* __restrict__ s1 = reinterpret_cast<const float4*>(xp_bytes + o1);
-        A[0] = s0[0]; B[0] = s0[1];
-        A[1] = s1[0]; B[1] = s1[1];
-    };
-    static_assert(kPackPairsPerTrip == 2, "the loop below");
-    // the loop, once per form of the pair term (GUARD: a special case of the law is possible for one of this wave's targets)
-    auto run = [&](auto guard) {
+    static_assert(kPackPairsPerTrip == 2, "the loops below");
+    // one form of the pair term per wave (GUARD: a special case of the law is possible for one of this wave's targets)
+    auto compute_with = [&](auto guard, const float4 (&A)[2], const float4 (&B)[2]) {
         constexpr bool GUARD = decltype(guard)::value;
         const f2 bias = GUARD ? f2{0.f, 0.f} : f2{kTiny, kTiny};
-        auto term = [&](const float4 A, const float4 B, const f2 x2, const f2 y2, const f2 z2, Sums<D>& S) {
-            const PairTerm<D> q(A, B, x2, y2, z2, bias);
+        auto term = [&](const float4 A1, const float4 B1, const f2 x2, const f2 y2, const f2 z2, Sums<D>& S) {
+            const PairTerm<D> q(A1, B1, x2, y2, z2, bias);
             f2 wgt;
             if (GUARD && __builtin_expect(q.template special<LAW>() != 0ull, 0)) wgt = q.template guarded<LAW>();
             else wgt = q.plain();
             S.add(q, wgt);
         };
-        auto compute = [&](const float4 (&A)[2], const float4 (&B)[2]) {
-            if (S0.pending + 4u > kFlushTerms) {
-                if (flushed) { S0.flush(); S1.flush(); } else { S0.store(); S1.store(); flushed = true; }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                term(A[j], B[j], ix2, iy2, iz2, S0);
-                term(A[j], B[j], jx2, jy2, jz2, S1);
-            }
-            S0.pending += 4u;
-        };
-        float4 A0[2], B0[2], A1[2], B1[2];
-        issue(0u, A0, B0);
-        // One back edge, no exit in the middle: with a `break` between the halves the compiler waits for EVERY outstanding load at
-        // the loop head (s_waitcnt vmcnt(0)); this way it waits for the four older ones only, the reload stays in flight.
-        uint32_t i = 0;
-        for (; i + 4u <= T; i += 4u) {                             // loads past the share's end fetch the next share's pairs or the pad pair: not used
-            issue(i + 2u, A1, B1);
-            compute(A0, B0);
-            issue(i + 4u, A0, B0);
-            compute(A1, B1);
+        if (S0.pending + 4u > kFlushTerms) {
+            if (flushed) { S0.flush(); S1.flush(); } else { S0.store(); S1.store(); flushed = true; }
         }
-        if (i < T) compute(A0, B0);                                // T is even: the last two pairs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            term(A[j], B[j], ix2, iy2, iz2, S0);
+            term(A[j], B[j], jx2, jy2, jz2, S1);
+        }
+        S0.pending += 4u;
     };
-    if (T) {                                                       // wave-uniform
+    if (expanded) {
+        // every lane of a leaf fills the entries q = lw, lw + w, ... of its leaf's row; lanes without a leaf fill the slack behind the
+        // last row (the loop's read-ahead must find loadable offsets there) and walk row 0 (their sums are never stored)
+        // RUN by run, straight from the plan's copy runs (no tables, no search): lane lw of a leaf takes its runs lw, lw + w, ... and
+        // writes their pairs' offsets (consecutive records, 32 bytes apart), then its share of the pad entries behind the stream's end
+        const uint32_t row = sub < n_sub ? sub * PT : 0u;
+        const uint32_t pad_off = a.pslots << 4;
+        if (sub < n_sub) {
+            for (uint32_t r = lw; r < my.op_n; r += w) {
+                const CopyOp o = a.ops[my.op_lo + r];
+                const uint32_t begin = r ? a.ops[my.op_lo + r - 1u].end : 0u;
+                uint32_t off = (o.base + begin) << 4;              // the run's first unit
+                for (uint32_t q = begin >> 1; q < (o.end >> 1); ++q, off += 32u) poff[row + q] = off;
+            }
+            const uint32_t stream_pairs = my.op_n ? a.ops[my.op_lo + my.op_n - 1u].end >> 1 : 0u;   // <= PT: T covers the wave's longest stream
+            for (uint32_t q = stream_pairs + lw; q < PT; q += w) poff[row + q] = pad_off;
+        }
+        if (lane < kPackExpandSlack) poff[n_sub * PT + lane] = pad_off;
+        __syncthreads();
+        const uint2* __restrict__ const mine = reinterpret_cast<const uint2*>(poff + row + g * T);   // T and PT are even: 8-byte aligned
+        auto issue = [&](const uint2 o, float4 (&A)[2], float4 (&B)[2]) {
+            const float4* __restrict__ s0 = reinterpret_cast<const float4*>(xp_bytes + o.x);
+            const float4* __restrict__ s1 = reinterpret_cast<const float4*>(xp_bytes + o.y);
+            A[0] = s0[0]; B[0] = s0[1];
+            A[1] = s1[0]; B[1] = s1[1];
+        };
+        auto run = [&](auto guard) {
+            float4 A0[2], B0[2], A1[2], B1[2];
+            uint2 o_now = mine[0], o_next = mine[1];               // the offsets run one stage ahead of the loads they address
+            issue(o_now, A0, B0);
+            uint32_t i = 0;
+            for (; i + 4u <= T; i += 4u) {                         // loads past the share's end fetch the next share's pairs or the pad pair: not used
+                issue(o_next, A1, B1);
+                o_now = mine[(i >> 1) + 2u];
+                compute_with(guard, A0, B0);
+                issue(o_now, A0, B0);
+                o_next = mine[(i >> 1) + 3u];
+                compute_with(guard, A1, B1);
+            }
+            if (i < T) compute_with(guard, A0, B0);                // T is even: the last two pairs
+        };
+        // Leaves of 3-4 bodies (two lanes to a lane group, which read the same records): the loads are what limits their waves (texture
+        // address unit 71 % busy, VALU 46 %: profiles/r5/pmc_pack_kernel.txt), so the two lanes of a group load ONE half of each
+        // 32-byte record each -- the even lane {xa,xb,ya,yb}, the odd lane {za,zb,ma,mb} -- and hand it to each other with DPP moves
+        // (quad_perm: a leaf's four lanes are one quad): half the load instructions for 16 more moves per loop body of 52.
+        auto run_shared = [&](auto guard) {
+            const uint32_t half = (lane & 1u) << 4;                // this lane's half of a record
+            auto issue_half = [&](const uint2 o, float4 (&H)[2]) {
+                H[0] = *reinterpret_cast<const float4*>(xp_bytes + (o.x + half));
+                H[1] = *reinterpret_cast<const float4*>(xp_bytes + (o.y + half));
+            };
+            auto from_even = [](const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true)); };   // quad_perm:[0,0,2,2]
+            auto from_odd = [](const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF5, 0xF, 0xF, true)); };    // quad_perm:[1,1,3,3]
+            auto compute_halves = [&](const float4 (&H)[2]) {
+                float4 A[2], B[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    A[j] = make_float4(from_even(H[j].x), from_even(H[j].y), from_even(H[j].z), from_even(H[j].w));
+                    B[j] = make_float4(from_odd(H[j].x), from_odd(H[j].y), from_odd(H[j].z), from_odd(H[j].w));
+                }
+                compute_with(guard, A, B);
+            };
+            float4 H0[2], H1[2];
+            uint2 o_now = mine[0], o_next = mine[1];
+            issue_half(o_now, H0);
+            uint32_t i = 0;
+            for (; i + 4u <= T; i += 4u) {
+                issue_half(o_next, H1);
+                o_now = mine[(i >> 1) + 2u];
+                compute_halves(H0);
+                issue_half(o_now, H0);
+                o_next = mine[(i >> 1) + 3u];
+                compute_halves(H1);
+            }
+            if (i < T) compute_halves(H0);
+        };
+        if (bp->shape == 1u && w == 4u && P == 2u) {               // wave-uniform: every leaf of the wave has W = 2 lanes per group
+            if (safe) run_shared(std::false_type{});
+            else run_shared(std::true_type{});
+        } else if (safe) run(std::false_type{});
+        else run(std::true_type{});
+    } else if (T) {
+        // the cursor loop (rounds 3-4): lane group g walks stream positions [2 g T, 2 (g + 1) T) of its leaf straight from the run tables
+        if (!valid) { run_end = 0xffffffffu; run_off = a.pslots << 4; run_mask = 0u; }   // no target: a pad run of its own
+        const uint32_t v_begin = 2u * g * T;
+        auto issue = [&](const uint32_t i, float4 (&A)[2], float4 (&B)[2]) {   // pairs i and i + 1 of this lane's share
+            const uint32_t v = v_begin + 2u * i;
+            const uint32_t o0 = offset_of(v), o1 = offset_of(v + 2u);
+            const float4* __restrict__ s0 = reinterpret_cast<const float4*>(xp_bytes + o0);
+            const float4* __restrict__ s1 = reinterpret_cast<const float4*>(xp_bytes + o1);
+            A[0] = s0[0]; B[0] = s0[1];
+            A[1] = s1[0]; B[1] = s1[1];
+        };
+        auto run = [&](auto guard) {
+            float4 A0[2], B0[2], A1[2], B1[2];
+            issue(0u, A0, B0);
+            // One back edge, no exit in the middle: with a `break` between the halves the compiler waits for EVERY outstanding load at
+            // the loop head (s_waitcnt vmcnt(0)); this way it waits for the four older ones only, the reload stays in flight.
+            uint32_t i = 0;
+            for (; i + 4u <= T; i += 4u) {                         // loads past the share's end fetch the next share's pairs or the pad pair: not used
+                issue(i + 2u, A1, B1);
+                compute_with(guard, A0, B0);
+                issue(i + 4u, A0, B0);
+                compute_with(guard, A1, B1);
+            }
+            if (i < T) compute_with(guard, A0, B0);                // T is even: the last two pairs
+        };
         if (safe) run(std::false_type{});
         else run(std::true_type{});
     }
@@ -494,13 +612,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAV
         const unsigned l0 = sub * w + t;
         for (unsigned h = 0; h < (valid1 ? 2u : 1u); ++h) {
             double ox = 0.0, oy = 0.0, oz = 0.0;
-            for (unsigned q = 0; q < P; ++q) { ox += osum[0][64u * h + l0 + q * W]; oy += osum[1][64u * h + l0 + q * W]; oz += osum[2][64u * h + l0 + q * W]; }
+            for (unsigned q = 0; q < P; ++q) { ox += osum[64u * h + l0 + q * W]; oy += osum[128u + 64u * h + l0 + q * W]; oz += osum[256u + 64u * h + l0 + q * W]; }
             const uint32_t pslot = h ? pslot1 : pslot0;
             a.acc[pslot] = ox;
             a.acc[(size_t)a.pslots + pslot] = oy;
             if (D == 3) a.acc[2 * (size_t)a.pslots + pslot] = oz;
         }
     }
+}
+
+template <int D, int LAW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAVES, 8))) void leaf_pack_kernel(LeafPackArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[kPackSmemBytes];
+    leaf_pack_body<D, LAW>(a, blockIdx.x, smem);
+}
+
+// A structure with BOTH kinds of workgroups -- packed waves and a few one-leaf workgroups (leaves whose lists have too many runs to
+// pack) -- in ONE launch: the first n_one workgroups are the one-leaf ones (the long ones: dispatched first), the others the packed
+// waves.  Two launches ran the 25 one-leaf workgroups of an 8-body structure alone for 8.7 us ahead of 85 us of packed waves
+// (profiles/r4/leaf_kernel_stats_final_8body.csv).  Both bodies use the same 64 lanes and the same LDS (the larger of the two).
+template <int D, int LAW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBX_PACK_WAVES, 8))) void leaf_fused_kernel(LeafArgs one, LeafPackArgs pack, uint32_t n_one) {
+    constexpr unsigned kBytes = pair_smem_bytes<1>() > kPackSmemBytes ? pair_smem_bytes<1>() : kPackSmemBytes;
+    __shared__ __attribute__((aligned(16))) char smem[kBytes];
+    if (blockIdx.x < n_one) leaf_pair_body<D, LAW, 1>(one, blockIdx.x, smem);
+    else leaf_pack_body<D, LAW>(pack, blockIdx.x - n_one, smem);
 }
 
 // The call's largest |mass| (as fp32 bits) into one word: the block's maximum through LDS, then ONE lane per block, and only when an
@@ -624,6 +760,14 @@ PackKernel pick_pack(int dim, int law) {
     static const PackKernel table[2][3] = {
         {leaf_pack_kernel<2, NBX_LAW_BRUTE>, leaf_pack_kernel<2, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<2, NBX_LAW_FMM_P2P>},
         {leaf_pack_kernel<3, NBX_LAW_BRUTE>, leaf_pack_kernel<3, NBX_LAW_TREE_LEAF>, leaf_pack_kernel<3, NBX_LAW_FMM_P2P>}};
+    return table[dim - 2][law];
+}
+
+typedef void (*FusedKernel)(LeafArgs, LeafPackArgs, uint32_t);
+FusedKernel pick_fused(int dim, int law) {
+    static const FusedKernel table[2][3] = {
+        {leaf_fused_kernel<2, NBX_LAW_BRUTE>, leaf_fused_kernel<2, NBX_LAW_TREE_LEAF>, leaf_fused_kernel<2, NBX_LAW_FMM_P2P>},
+        {leaf_fused_kernel<3, NBX_LAW_BRUTE>, leaf_fused_kernel<3, NBX_LAW_TREE_LEAF>, leaf_fused_kernel<3, NBX_LAW_FMM_P2P>}};
     return table[dim - 2][law];
 }
 
@@ -1004,17 +1148,22 @@ int plan_mark_done(nbx_leaf_plan* p, hipStream_t s) {
 int plan_launch_pairs(nbx_leaf_plan* p, int law, hipStream_t s, bool timed) {
     if (p->n_blocks == 0 && p->n_packs == 0) return NBX_OK;
     if (timed) NBX_HIP_TRY(hipEventRecord(p->ev0, s));
-    if (p->n_blocks) {
-        LeafArgs a;
-        a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
-        hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
+    LeafArgs a;
+    a.xp = p->xp; a.pslots = (uint32_t)p->pslots; a.ops = p->ops; a.blocks = p->blocks; a.acc = p->sums; a.max_mass_bits = p->max_mass;
+    LeafPackArgs pa;
+    pa.xp = p->xp; pa.pslots = (uint32_t)p->pslots; pa.ops = p->ops; pa.blocks = p->packs; pa.subs = p->subs; pa.acc = p->sums; pa.max_mass_bits = p->max_mass;
+    if (p->n_blocks && p->n_packs && p->waves == 1) {   // both kinds (packing implies one-wave workgroups): one launch, the one-leaf workgroups first
+        hipLaunchKernelGGL(pick_fused(p->dim, law), dim3((unsigned)(p->n_blocks + p->n_packs)), dim3(64), 0, s, a, pa, (uint32_t)p->n_blocks);
         NBX_HIP_TRY(hipGetLastError());
-    }
-    if (p->n_packs) {
-        LeafPackArgs pa;
-        pa.xp = p->xp; pa.pslots = (uint32_t)p->pslots; pa.ops = p->ops; pa.blocks = p->packs; pa.subs = p->subs; pa.acc = p->sums; pa.max_mass_bits = p->max_mass;
-        hipLaunchKernelGGL(pick_pack(p->dim, law), dim3((unsigned)p->n_packs), dim3(64), 0, s, pa);
-        NBX_HIP_TRY(hipGetLastError());
+    } else {
+        if (p->n_blocks) {
+            hipLaunchKernelGGL(pick(p->dim, law, p->waves), dim3((unsigned)p->n_blocks), dim3(64u * (unsigned)p->waves), 0, s, a);
+            NBX_HIP_TRY(hipGetLastError());
+        }
+        if (p->n_packs) {
+            hipLaunchKernelGGL(pick_pack(p->dim, law), dim3((unsigned)p->n_packs), dim3(64), 0, s, pa);
+            NBX_HIP_TRY(hipGetLastError());
+        }
     }
     if (timed) NBX_HIP_TRY(hipEventRecord(p->ev1, s));
     return NBX_OK;

@@ -68,9 +68,12 @@ constexpr size_t kPackWindowWaves = NBX_PACK_WINDOW_WAVES;   // waves whose leav
 #ifndef NBX_PACK_SIX_LANES
 #define NBX_PACK_SIX_LANES 6    /* A/B: 8 = leaves of 5-6 bodies share the 7-8-body class (8 lanes, two of them idle) */
 #endif
+#ifndef NBX_PACK_EIGHT_LANES
+#define NBX_PACK_EIGHT_LANES 8   /* A/B: 4 = leaves of 7-8 bodies on 4 lanes, ONE lane group (16 leaves to a wave, twice the trips) */
+#endif
 constexpr int kPackClasses = 5;                 // 1-2, 3-4, 5-6, 7-8, 9-16 bodies
-constexpr uint32_t kPackLanes[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, NBX_PACK_SIX_LANES, 8u, 16u};
-constexpr uint32_t kPackGroups[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, 2u, 2u};
+constexpr uint32_t kPackLanes[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES, NBX_PACK_SIX_LANES, NBX_PACK_EIGHT_LANES, 16u};
+constexpr uint32_t kPackGroups[kPackClasses] = {NBX_PACK_TINY_LANES, NBX_PACK_SMALL_LANES / 2u, 2u, NBX_PACK_EIGHT_LANES / 4u, 2u};
 constexpr int kPackMaxSubs = 16;                // leaves to a wave at most: the packed kernel's LDS run tables and the layout's window keys are sized for it
 constexpr bool pack_classes_fit() {
     for (int k = 0; k < kPackClasses; ++k) {
