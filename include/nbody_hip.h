@@ -70,7 +70,7 @@ int nbx_device_count(int* count);
  * first solver call -- the way OpenMP's thread pool is already up when the reference times its CPU rows. */
 int nbx_warmup(int device);
 /* The library keeps a few idle HIP streams per device, the RCCL communicators of destroyed nodes, the device allocations of the last
- * two destroyed contexts per device (up to 64 MiB each), and the device allocation of
+ * two destroyed contexts per device (up to 1 GiB each: a context of N = 2^20 bodies holds ~0.3 GB, most of it the mixed mode's fp64 sums), and the device allocation of
  * the last nbx_leaf_pair_forces call per device (up to 2 GiB), for the next
  * context / node / call on the same devices (creating a stream costs ~1.4 ms and destroying one up to 3 ms on this runtime,
  * a communicator set for 8 GPUs far more -- against a force evaluation of 0.07 ms at N = 1,000).  This gives them

@@ -541,6 +541,8 @@ __device__ __forceinline__ void leaf_pack_body(const LeafPackArgs& a, const unsi
         // address unit 71 % busy, VALU 46 %: profiles/r5/pmc_pack_kernel.txt), so the two lanes of a group load ONE half of each
         // 32-byte record each -- the even lane {xa,xb,ya,yb}, the odd lane {za,zb,ma,mb} -- and hand it to each other with DPP moves
         // (quad_perm: a leaf's four lanes are one quad): half the load instructions for 16 more moves per loop body of 52.
+        // Measured and lost (profiles/r5/leaf_small_leaves.txt): the same exchange for EVERY class through ds_bpermute_b32 (no VALU
+        // instruction added, but its latency sits between the loads and the arithmetic): 8-body leaves 0.315 -> 0.265, 4-body cells 0.161 -> 0.152.
         auto run_shared = [&](auto guard) {
             const uint32_t half = (lane & 1u) << 4;                // this lane's half of a record
             auto issue_half = [&](const uint2 o, float4 (&H)[2]) {
@@ -899,6 +901,7 @@ struct nbx_leaf_plan {
     // masses of the last evaluation: a context's m64 (stride 1) or the staged bodies (offset 2 dim, stride the body's)
     const double* last_mass = nullptr;
     size_t last_mass_stride = 1;
+    unsigned long long last_ctx_id = 0;   // the context whose m64 last_mass points into (0: the plan's own staged bodies)
     bool forces_in_arena = false;   // `forces` is a piece of the arena (the one-shot call's plan), not an allocation of its own
     bool device_planned = false;    // laid out on the device (leaf_plan_device.h); false: on the host (leaf_plan.h)
     char* raw_arena = nullptr;      // one-shot call: the staged bodies come from the parked pool instead of hipMalloc
@@ -1170,6 +1173,8 @@ int plan_launch_pairs(nbx_leaf_plan* p, int law, hipStream_t s, bool timed) {
 }
 
 int plan_forces_out(nbx_leaf_plan* p, hipStream_t s, double* forces_out) {
+    if (p->last_ctx_id && !nbx::ctx_alive(p->last_ctx_id))   // the masses were read where the evaluation found them: in a context that is gone
+        return fail(NBX_ERR_STATE, "the context of the last evaluation no longer exists: evaluate again before asking for forces");
     if (!p->forces && p->n) NBX_HIP_TRY(hipMalloc((void**)&p->forces, p->n * (size_t)p->dim * sizeof(double)));
     if (p->n) {
         hipLaunchKernelGGL(leaf_forces_by_body_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, s, p->sums, (uint32_t)p->pslots,
@@ -1366,7 +1371,7 @@ int nbx_leaf_plan_forces(nbx_leaf_plan* p, const void* bodies, size_t stride_byt
     if ((rc = plan_launch_pairs(p, law, s, true))) return rc;
     p->evaluated = true; p->last_law = law;
     p->last_signedG = (law == NBX_LAW_BRUTE) ? -G : G;   // brute force: forces[i] -= f (methods.cpp:131); tree codes: += (attractive)
-    p->last_mass = p->raw + 2 * p->dim; p->last_mass_stride = stride_bytes / sizeof(double);
+    p->last_mass = p->raw + 2 * p->dim; p->last_mass_stride = stride_bytes / sizeof(double); p->last_ctx_id = 0;
     if ((rc = plan_mark_done(p, s))) return rc;
     if ((rc = plan_forces_out(p, s, forces_out))) return rc;
     if (kernel_ms && (p->n_blocks || p->n_packs)) NBX_HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
@@ -1403,7 +1408,7 @@ int nbx_leaf_plan_forces_ctx(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, do
     if ((rc = plan_launch_pairs(p, law, s, kernel_ms != nullptr))) return rc;
     p->evaluated = true; p->last_law = law;
     p->last_signedG = (law == NBX_LAW_BRUTE) ? -G : G;
-    p->last_mass = c->m64; p->last_mass_stride = 1;
+    p->last_mass = c->m64; p->last_mass_stride = 1; p->last_ctx_id = c->id;
     if ((rc = plan_mark_done(p, s))) return rc;
     if (forces_out) { if ((rc = plan_forces_out(p, s, forces_out))) return rc; }
     else if (kernel_ms) NBX_HIP_TRY(hipStreamSynchronize(s));
@@ -1428,7 +1433,7 @@ int nbx_leaf_plan_kick_drift(nbx_leaf_plan* p, nbx_ctx* c, double dt) {
     if (!p->evaluated) return fail(NBX_ERR_STATE, "evaluate the leaf sums before kick_drift");
     if (c->device != p->device || c->dim != p->dim || c->n_total != p->n || c->n_shards != 1)
         return fail(NBX_ERR_INVALID, "the context must be a single-shard context of the plan's device, dimension and body count");
-    if (p->last_mass != c->m64) return fail(NBX_ERR_STATE, "the last evaluation was not made from this context");
+    if (p->last_ctx_id != c->id) return fail(NBX_ERR_STATE, "the last evaluation was not made from this context");
     DeviceScope scope;
     int rc = plan_set_device(p);
     if (rc) return rc;
@@ -1476,7 +1481,7 @@ int nbx_leaf_plan_step(nbx_leaf_plan* p, nbx_ctx* c, int law, double G, double d
         if ((rc = plan_enqueue_step(p, c, law, signedG, dt, s))) return rc;
     p->evaluated = true; p->last_law = law;
     p->last_signedG = signedG;
-    p->last_mass = c->m64; p->last_mass_stride = 1;
+    p->last_mass = c->m64; p->last_mass_stride = 1; p->last_ctx_id = c->id;
     c->have_accel = false;                          // the context's own accelerations (if any) belong to the old positions
     c->tgt_cand_valid = 0; c->bad_list_pass = -1;
     return plan_mark_done(p, s);

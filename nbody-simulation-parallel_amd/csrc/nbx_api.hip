@@ -77,7 +77,10 @@ void park_stream(int device, hipStream_t s) {   // s is idle: the caller has syn
 namespace {
 struct ParkedCtxArena { int device; char* p; size_t bytes; };
 std::vector<ParkedCtxArena> g_ctx_arenas;   // under g_stream_pool_mu
-constexpr size_t kArenaParkMaxBytes = (size_t)64 << 20;
+// 1 GiB: since the mixed mode became the default a context's block carries the fp64 pass's sums (8 x dim x pad doubles: 201 MB at
+// N = 2^20, 805 MB at 2^22), and a one-shot call per step at such sizes would otherwise hipMalloc and hipFree hundreds of MB each
+// time -- the cost the parking exists to avoid.  288 GB of HBM do not miss two idle blocks; nbx_release_cached() frees them.
+constexpr size_t kArenaParkMaxBytes = (size_t)1 << 30;
 constexpr size_t kArenasParkedPerDevice = 2;
 }  // namespace
 
@@ -135,6 +138,19 @@ void release_parked_ctx_arenas() {
         if (hipSetDevice(e.device) == hipSuccess) (void)hipFree(e.p);
     if (have) (void)hipSetDevice(before);
     (void)hipGetLastError();
+}
+
+// the ids of the live contexts (a plan's last evaluation names its context by id: the arena of a destroyed context is parked and
+// handed to the next one, so an address says nothing)
+namespace {
+std::mutex g_ctx_mu;
+std::vector<unsigned long long> g_live_ctx;
+std::atomic<unsigned long long> g_next_ctx_id{1};
+}  // namespace
+bool ctx_alive(unsigned long long id) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (unsigned long long v : g_live_ctx) if (v == id) return true;
+    return false;
 }
 
 void release_parked_streams() {
@@ -616,6 +632,11 @@ int nbx_ctx_create(nbx_ctx** out, int device, int dim, size_t n_total, int n_sha
     if (rc != NBX_OK) return rc;
     if (device < 0 || device >= ndev) return fail(NBX_ERR_NO_DEVICE, "device ordinal out of range");
     nbx_ctx* c = new (std::nothrow) nbx_ctx();
+    if (c) {
+        c->id = g_next_ctx_id.fetch_add(1);
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        try { g_live_ctx.push_back(c->id); } catch (...) { delete c; c = nullptr; }
+    }
     if (!c) return fail(NBX_ERR_ALLOC, "host allocation failed");
     c->device = device; c->dim = dim; c->n_total = n_total; c->n_shards = n_shards; c->shard = shard;
     c->shard_len = (n_total + (size_t)n_shards - 1) / (size_t)n_shards;
@@ -698,6 +719,11 @@ int nbx_ctx_destroy(nbx_ctx* c) {
     if (c->own_stream) {
         if (hipStreamSynchronize(c->own_stream) == hipSuccess) park_stream(c->device, c->own_stream);
         else (void)hipStreamDestroy(c->own_stream);
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        for (size_t i = 0; i < g_live_ctx.size(); ++i)
+            if (g_live_ctx[i] == c->id) { g_live_ctx[i] = g_live_ctx.back(); g_live_ctx.pop_back(); break; }
     }
     delete c;
     return NBX_OK;

@@ -8,6 +8,7 @@
 #include "nbx_internal.h"
 
 struct nbx_ctx {
+    unsigned long long id = 0;   // unique per context ever created in this process (never reused: a leaf plan remembers WHICH context its last evaluation read, not where it lived)
     int device = 0, dim = 3, n_shards = 1, shard = 0;
     size_t n_total = 0, shard_len = 0, count = 0;  // count = real bodies in this shard
     unsigned pad = 0;
@@ -123,6 +124,7 @@ void release_parked_ctx_arenas();
 int upload_stage(nbx_ctx* c, const void* bodies, size_t stride_bytes, bool only_own, unsigned long long facts[3],
                  bool bodies_is_own_slice = false);   // true: `bodies` points at this shard's first body, not at body 0
 int upload_finish(nbx_ctx* c, const unsigned long long facts[3]);
+bool ctx_alive(unsigned long long id);  // nbx_api.hip: a context with this id exists (created, not yet destroyed)
 void release_parked_communicators();   // nbx_node.hip
 void release_parked_leaf_arenas();     // leaf_pair_kernel.hip
 }  // namespace nbx

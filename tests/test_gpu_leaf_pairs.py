@@ -331,6 +331,29 @@ def test_invalid_structures_are_rejected_before_any_launch(nbx, oracle):
     assert nbx.leaf_pair_forces_hip(np.zeros((0, 7)), np.array([0]), np.zeros(0), np.array([0]), np.zeros(0)).shape == (0, 3)
 
 
+def test_a_plan_names_its_context_by_identity_not_by_address(nbx, oracle):
+    """the arena of a destroyed context is parked and handed to the next one of the same size, so an address cannot say
+    which context an evaluation read.  The plan remembers the context's id: forces after the context is gone are refused, and a
+    new context (same address or not) is not mistaken for the old one."""
+    n = 4096
+    b = oracle.round_inputs_to_f32(oracle.generate(31, n, 3))
+    leaves = nbx.leaves.uniform_grid_leaves(b, 3, 2)
+    with nbx.LeafPlan(n, 3, *leaves) as plan:
+        c = nbx.Context(n, 3)
+        c.upload(b)
+        want = plan.forces_ctx(c, nbx.LAW_TREE_LEAF, oracle.G)
+        plan.forces_ctx(c, nbx.LAW_TREE_LEAF, oracle.G, fetch=False)
+        c.close()
+        with pytest.raises(nbx.NbxError):
+            plan.get_forces()                       # the masses lived in the context
+        with nbx.Context(n, 3) as c2:               # takes the parked arena: very likely the same addresses
+            c2.upload(b * np.r_[np.ones(6), 2.0])   # other masses
+            with pytest.raises(nbx.NbxError):
+                plan.kick_drift(c2, 1.0)            # never evaluated from THIS context
+            got = plan.forces_ctx(c2, nbx.LAW_TREE_LEAF, oracle.G)
+            assert np.allclose(got, 4.0 * want, rtol=1e-12)   # m_i m_j both doubled; the plan read c2's masses
+
+
 def test_leaf_kernel_timing_at_fmm_like_sizes(nbx, oracle):
     """N = 2^20, leaves of <= ~100 bodies (FMM_MAX_BODIES_PER_LEAF, methods.h:26), 27-cell lists: EVERY body against the
     oracle (8.7e8 pair terms, a few seconds of its OpenMP loop), and the kernel's own time."""
