@@ -172,6 +172,17 @@ def leaf_pair_roofline(device):
         sl = build()
         ssz = np.diff(sl[0]).astype(np.int64)
         sp = int((ssz * np.add.reduceat(ssz[sl[3]], sl[2][:-1])).sum())
+        # what a caller that rebuilds its tree per evaluation pays (the reference does: methods.cpp:377-401): a NEW plan for the
+        # structure (validation + layout on the device + buffers; the previous plan destroyed first), and the whole one-shot call
+        remake, oneshot = 1e30, 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            with nbx.LeafPlan(n, 3, *sl, device=device):
+                remake = min(remake, (time.perf_counter() - t0) * 1e3)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            nbx.leaf_pair_forces_hip(b, *sl, law=law, device=device)
+            oneshot = min(oneshot, (time.perf_counter() - t0) * 1e3)
         with nbx.LeafPlan(n, 3, *sl, device=device) as plan, nbx.Context(n, 3, device=device) as ctx:
             ctx.upload(b)
             ctx.synchronize()
@@ -183,8 +194,11 @@ def leaf_pair_roofline(device):
             many = plan.time_kernel(law, 300)
             slots, runs, groups, waves = plan.info()
         by_size.append({"workload": f"N={n}, {ssz.size} {label} (mean {ssz.mean():.1f})", "pair_terms_per_launch": sp,
-                        "kernel": "leaf_pack_kernel<3, NBX_LAW_TREE_LEAF> (several leaves to a wave)" if ssz.mean() <= 8.0 else "leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 1>",
+                        "kernel": "leaf_pack_kernel / leaf_fused_kernel<3, NBX_LAW_TREE_LEAF> (several leaves to a wave)" if ssz.mean() <= 8.0 else "leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 1>",
                         "workgroups": int(groups), "kernel_ms": one, "frac": sp * 20.0 / (one * 1e-3) / 1e12 / 157.3,
+                        "new_plan_ms": remake, "one_shot_call_ms": oneshot,
+                        "new_plan_means": "nbx_leaf_plan_create wall time, best of 3 (CSR arrays from host memory, layout on the device: csrc/leaf_plan_device.h); "
+                                          "one_shot_call_ms = nbx_leaf_pair_forces wall time, best of 3 (58 MB of bodies in, 25 MB of forces out)",
                         "back_to_back": {"kernel_ms": many, "frac": sp * 20.0 / (many * 1e-3) / 1e12 / 157.3}})
     return {"kernel": "leaf_pair_kernel<3, NBX_LAW_TREE_LEAF, 2>", "workload": f"N={n}, {sizes.size} grid leaves (mean {sizes.mean():.1f} bodies), 27-cell lists",
             "entry": "nbx_leaf_plan_forces_ctx (resident plan + resident bodies)", "law_pin": "TREE_LEAF: pinned on the reference's own BVH leaves (tests/golden/bvh_leaves_*.npz)",
@@ -558,7 +572,7 @@ def main():
                          "shader_mhz_detail": dict(held, source="in-kernel stamps (s_memtime / s_memrealtime) of the last timed force launch, "
                                                    "one pair per workgroup, nbx_ctx_shader_clock") if held else "not measured (kernel variant without stamps)",
                          "frac_at_held_clock": achieved_tflops / (PEAK_FP32_TFLOPS * held["median_mhz"] / SHADER_PEAK_MHZ) if held else None,
-                         "this_box_ceiling": dict(ceiling, kernel="pure v_pk_fma_f32 stream, 16 chains per lane, 3 waves per SIMD, ~50 ms right after the "
+                         "this_box_ceiling": dict(ceiling, kernel="pure v_pk_fma_f32 stream, 16 chains per lane, every CU full, ~50 ms right after the "
                                                   "timed steps (nbx_measure_valu_ceiling)") if ceiling else None,
                          "frac_of_this_box_ceiling": achieved_tflops / ceiling["tflops"] if ceiling else None,
                          "note": "arithmetic intensity ~7.5e5 flop/B: HBM-light; compare runs across boxes by frac_at_held_clock / frac_of_this_box_ceiling, not by frac",

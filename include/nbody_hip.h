@@ -374,7 +374,7 @@ int nbx_variant_kernel_symbol(int variant, int dim, int mixed_mode, char* buf, s
  * nbx_ctx_shader_clock synchronises the stream.  Any out pointer may be NULL. */
 int nbx_ctx_enable_clock_stamps(nbx_ctx* ctx, int on);
 int nbx_ctx_shader_clock(nbx_ctx* ctx, double* median_mhz, double* min_mhz, double* max_mhz, int* workgroups);
-/* The same box's ceiling: a pure v_pk_fma_f32 stream (16 independent chains per lane, three waves per SIMD on every CU)
+/* The same box's ceiling: a pure v_pk_fma_f32 stream (16 independent chains per lane, 24 workgroups of 256 lanes per CU, as many resident as fit)
  * for about target_ms (1..2000) on `device`; *tflops = what it achieved (4 flop per lane-instruction), *shader_mhz = the
  * clock it held.  The guide's 157.3 TFLOP/s assumes 2.4 GHz and one packed FMA per cycle per lane pair. */
 int nbx_measure_valu_ceiling(int device, double target_ms, double* tflops, double* shader_mhz);

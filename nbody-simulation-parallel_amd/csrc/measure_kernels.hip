@@ -59,11 +59,14 @@ extern "C" int nbx_measure_valu_ceiling(int device, double target_ms, double* tf
     std::vector<unsigned long long> host;
     std::vector<double> mhz;
     hipDeviceProp_t prop;
-    int grid = 0, iters = 20000;
+    int grid = 0, iters = 2500;
     float ms = 0.f;
     M_TRY(hipSetDevice(device));
     M_TRY(hipGetDeviceProperties(&prop, device));
-    grid = prop.multiProcessorCount * 3;   // three workgroups of four waves per CU = three waves per SIMD, the force kernel's occupancy
+    // 24 workgroups per CU, as many resident as fit (eight: two waves per SIMD each), the rest backfilled as they finish: a grid that
+    // fills the chip exactly once leaves the time to the dispatcher's placement (3 workgroups per CU on average, 4 on some: measured
+    // 98 TFLOP/s where the same chip makes 123)
+    grid = prop.multiProcessorCount * 24;
     M_TRY(hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(float)));
     M_TRY(hipMalloc((void**)&stamps, (size_t)grid * 2 * sizeof(unsigned long long)));
     M_TRY(hipEventCreate(&e0));

@@ -243,6 +243,32 @@ def test_workgroups_of_a_class_are_dealt_to_the_xcds_in_runs(planner_xcd, tmp_pa
     assert _check_xcd_runs(packs[:, 4], packs[:, 0]) >= 2
 
 
+def test_launch_order_is_lexicographic_in_duration_level_and_shape(planner, tmp_path):
+    """the order key used to be trips * 8 + shape quantised into 1,024 classes, so from trips >= 128 on waves of different
+    shapes shared a class (and were dealt to the XCDs side by side).  Now: (duration level, shape), lexicographic.  Long streams
+    (one merged run of ~140 consecutive leaves) on leaves of two size classes."""
+    rng = np.random.default_rng(5)
+    sizes = np.where(np.arange(1200) % 3 == 0, 8, 4)                     # size classes 3 (7-8 bodies) and 1 (3-4 bodies)
+    lo = np.concatenate([[0], np.cumsum(sizes)])
+    lb = rng.permutation(int(lo[-1]))
+    lists = []
+    for t in range(sizes.size):
+        start = int(rng.integers(0, sizes.size - 160))
+        lists.append(np.arange(start, start + 120 + (t * 7) % 40))       # consecutive leaves: ONE run, 600-900 units, trips 150-230
+    so = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    ss = np.concatenate(lists)
+    plan = planner(str(tmp_path), lo, lb, so, ss)
+    _check(plan, lo, lb, so, ss)
+    packs = plan["pack_blocks"].astype(np.int64)                         # sub_lo, n_sub, w, P, trips, inv_w, longest, shape
+    assert packs.shape[0] > 50 and packs[:, 4].min() >= 128 and set(packs[:, 7]) == {1, 3}
+    longest = int(packs[:, 4].max())
+    level = 1023 - packs[:, 4] * 1023 // longest
+    key = level * 8 + packs[:, 7]
+    assert (np.diff(key) >= 0).all(), "waves must be ordered by (duration level, shape)"
+    for k in np.unique(key):                                             # a class never mixes shapes
+        assert len(set(packs[key == k, 7])) == 1
+
+
 def test_the_layout_does_not_depend_on_the_number_of_threads(planner, planner_threads, tmp_path):
     """csrc/leaf_plan.h lays the copy runs and the packed waves out on up to 8 threads (ranges of leaves of equal list length; windows
     of packed leaves); every array of the plan must come out as from one thread.  (Under ASan + UBSan, like the rest of this file.)"""
