@@ -110,11 +110,23 @@ def cpu_baseline(n_bodies, dim, seed, budget_s=10.0, n_sample=0):
             counts = [threads] + ([host["physical_cores_usable"]] if host["physical_cores_usable"] > threads else [])
             for c in counts:
                 env = dict(os.environ, OMP_NUM_THREADS=str(c), PARLAY_NUM_THREADS=str(c), OMP_PROC_BIND="spread", OMP_PLACES="cores")
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(c), "--bodies", str(n_s),
-                                    "--dim", str(dim), "--seed", str(seed)], env=env, capture_output=True, text=True, timeout=3000 if n_sample else 600)
+                p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(c), "--bodies", str(n_s),
+                                      "--dim", str(dim), "--seed", str(seed)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                t_child = time.perf_counter()
+                while True:     # a sign of life per minute on stderr: a full-N baseline is silent for five minutes per solver
+                    try:
+                        out, err = p.communicate(timeout=60)
+                        break
+                    except subprocess.TimeoutExpired:
+                        sys.stderr.write(f"[bench] cpu baseline ({c} threads, {n_s} bodies): {time.perf_counter() - t_child:.0f} s so far\n")
+                        sys.stderr.flush()
+                        if time.perf_counter() - t_child > (3000 if n_sample else 600):
+                            p.kill()
+                            p.communicate()
+                            raise RuntimeError("cpu baseline child timed out")
                 if p.returncode:
-                    raise RuntimeError(p.stderr[-300:])
-                runs += [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+                    raise RuntimeError(err[-300:])
+                runs += [json.loads(l) for l in out.splitlines() if l.startswith("{")]
             first = runs[0]
             return {"value": first["value"], "unit": "pair-interactions/s", "cores": first["threads"], "kind": "reference",
                     "sample": f"reference {first['solver']} object code (oracle/_ref) on the first {n_s} bodies of the workload, "

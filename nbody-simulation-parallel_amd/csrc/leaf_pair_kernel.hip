@@ -403,17 +403,18 @@ struct LeafPackArgs {
 #ifndef NBX_PACK_EXPAND
 #define NBX_PACK_EXPAND 1280
 #endif
-constexpr unsigned kPackExpand = NBX_PACK_EXPAND;           // offsets per wave: 5 KB; with the run tables 9.3 KB of LDS per wave, 17 waves per CU
+constexpr unsigned kPackExpand = NBX_PACK_EXPAND;           // offsets per wave (5 KB; they share their LDS with the cursor loop's run tables: 8.2 KB per wave with the closing sums)
 constexpr unsigned kPackExpandSlack = 8;         // the pipelined loop reads offsets up to 6 entries past its share
 constexpr unsigned kPackTableWords = 2u * kPackMaxSubs * (kPackMaxOps + 1);
-constexpr unsigned kPackSmemBytes = (kPackTableWords + kPackExpand + kPackExpandSlack) * 4u;
+// LDS of a packed wave: ONE region for the cursor loop's run tables or the expanded loop's offsets (a wave runs one of the two loops),
+// and the closing sums behind it
+constexpr unsigned kPackLoopWords = kPackTableWords > kPackExpand + kPackExpandSlack ? kPackTableWords : kPackExpand + kPackExpandSlack;
+constexpr unsigned kPackSmemBytes = kPackLoopWords * 4u + 3u * 128u * (unsigned)sizeof(double);
 template <int D, int LAW>
 __device__ __forceinline__ void leaf_pack_body(const LeafPackArgs& a, const unsigned block, char* __restrict__ smem) {
-    constexpr unsigned kTableWords = kPackTableWords;
-    static_assert(kTableWords * 4u >= 3u * 128u * sizeof(double) && (kPackExpand + kPackExpandSlack) * 4u >= 3u * 128u * sizeof(double), "either region can hold the closing sums");
-    static_assert(kTableWords % 4u == 0u, "the offsets behind the tables are read as 8-byte pairs");
-    uint32_t* const tables = reinterpret_cast<uint32_t*>(smem);                 // the leaves' copy runs; the expanded path's closing sums afterwards
-    uint32_t* const poff = tables + kTableWords;                                // expanded pair offsets; the cursor path's closing sums
+    static_assert(kPackLoopWords % 4u == 0u, "the closing sums behind the loop's region are doubles");
+    uint32_t* const tables = reinterpret_cast<uint32_t*>(smem);                 // the cursor loop: the leaves' copy runs
+    uint32_t* const poff = tables;                                              // the expanded loop: the pair offsets (same region)
     uint32_t (*op_end)[kPackMaxOps + 1] = reinterpret_cast<uint32_t (*)[kPackMaxOps + 1]>(tables);
     uint32_t (*op_base)[kPackMaxOps + 1] = reinterpret_cast<uint32_t (*)[kPackMaxOps + 1]>(tables + kPackMaxSubs * (kPackMaxOps + 1));
     const unsigned lane = threadIdx.x;
@@ -456,7 +457,7 @@ __device__ __forceinline__ void leaf_pack_body(const LeafPackArgs& a, const unsi
     }
     Sums<D> S0, S1;
     bool flushed = false;                                          // wave-uniform: the fp64 sums hold something (they are not zeroed: the first flush stores)
-    double* const osum = reinterpret_cast<double*>(expanded ? tables : poff);   // [component][second target? 64 : 0][lane], in the region the loop does not use
+    double* const osum = reinterpret_cast<double*>(smem + kPackLoopWords * 4u);   // [component][second target? 64 : 0][lane]
     S0.o = osum + lane;
     S1.o = osum + 64u + lane;
     S0.stride = S1.stride = 128u;
