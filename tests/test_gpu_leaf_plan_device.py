@@ -67,6 +67,23 @@ def test_ragged_structures_word_for_word(check, tmp_path):
         assert p.returncode == 0 and p.stdout.startswith("identical"), f"{name}: {p.stdout[-600:]} {p.stderr[-300:]}"
 
 
+def test_random_structures_word_for_word(check, tmp_path):
+    """Thirty random structures (sizes, list lengths, share of empty leaves and of merged runs drawn per case): the device plan equals
+    the host plan word for word on every one."""
+    rng = np.random.default_rng(2025)
+    for k in range(30):
+        n_leaves = int(rng.integers(1, 4000))
+        top = int(rng.choice([3, 9, 17, 40, 130, 300]))
+        sizes = rng.integers(0 if rng.random() < 0.5 else 1, top + 1, n_leaves)
+        if sizes.sum() == 0:
+            sizes[0] = 1
+        longest = int(rng.choice([1, 5, 30, 90]))
+        lens = rng.integers(0, longest + 1, n_leaves)
+        leaves, n = _structure(1000 + k, sizes.tolist(), lambda t: int(lens[t]))
+        p = check(str(tmp_path / f"case{k}"), leaves, n)
+        assert p.returncode == 0 and p.stdout.startswith("identical"), f"case {k} ({n_leaves} leaves of up to {top}, lists up to {longest}): {p.stdout[-600:]} {p.stderr[-300:]}"
+
+
 def test_the_reference_trees_shapes_word_for_word_and_timed(check, tmp_path, nbx):
     """N = 2^20: the BVH's 16-body leaves, 8-body leaves and 4-body grid cells -- the rows of VERDICT r4 item 2 -- identical, and the
     device layout's stream time (copies of the four arrays included) printed for the record."""
