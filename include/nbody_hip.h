@@ -135,9 +135,11 @@ int nbx_leapfrog(void* bodies, size_t n, int dim, size_t body_stride_bytes,
  *       NBX_LAW_FMM_P2P    fmm_parlay.cpp:992-1020: force += ...; identical positions (|d_k| <= 1e-14) skipped; for
  *                          r^2 < 1e-10 the magnitude uses r^2 + (1e-5)^2 while the direction stays d/|d|
  * forces_out: n x Vector<dim>, zero for bodies in no leaf.  fp32 pair terms on leaf-ordered source pairs, fp64 sums;
- * every index array is validated on the host before anything is launched (NBX_ERR_INVALID).  kernel_ms (optional)
- * receives the pair kernel's duration (hipEvent).  This one-shot form validates, lays out and uploads the structure on every
- * call; a tree code that evaluates its leaf sums every step from resident bodies uses the PLAN below. */
+ * every index array is validated before the pair kernels follow it (NBX_ERR_INVALID: on the host for small structures; larger
+ * ones are laid out ON THE DEVICE, csrc/leaf_plan_device.h, where every index is checked before it is dereferenced and the
+ * refusal comes back with the layout's 64-byte summary).  kernel_ms (optional) receives the pair kernel's duration (hipEvent).
+ * This one-shot form validates, lays out and uploads the structure on every call (2.4-3.1 ms at N = 2^20, 84 MB of it PCIe);
+ * a tree code that evaluates its leaf sums every step from resident bodies uses the PLAN below. */
 enum { NBX_LAW_BRUTE = 0, NBX_LAW_TREE_LEAF = 1, NBX_LAW_FMM_P2P = 2 };
 int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t body_stride_bytes,
                          const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
@@ -148,9 +150,12 @@ int nbx_leaf_pair_forces(const void* bodies, size_t n, int dim, size_t body_stri
  * The reference's tree codes evaluate their leaf sums in EVERY force evaluation, from bodies that stay where they are
  * (bvh.cpp:143-176 BVH::calculate_force per body over the leaves its traversal accepts; fmm_parlay.cpp:916-1022 p2p_phase per
  * step) while the leaf structure changes only when the tree is rebuilt.  A plan is that structure made resident: the CSR
- * arrays are validated ONCE, the launch is laid out once (leaf-ordered slots, copy runs, workgroup table: csrc/leaf_plan.h)
+ * arrays are validated ONCE, the launch is laid out once (leaf-ordered slots, copy runs, workgroup tables: on the device,
+ * csrc/leaf_plan_device.h, or -- small structures -- on the host, csrc/leaf_plan.h; the two make the same plan word for word)
  * and stays on `device` with the buffers the kernels need; each evaluation then only re-gathers positions and runs the pair
- * kernel.  Arguments as for nbx_leaf_pair_forces.  A plan is bound to its device, dim and body count; not thread-safe. */
+ * kernel.  A caller that rebuilds its tree per evaluation, as the reference does (methods.cpp:377-401), makes a new plan per
+ * evaluation: 0.5-1.2 ms at N = 2^20.  NBODY_HIP_LEAF_PLANNER=host|device in the environment forces one planner.
+ * Arguments as for nbx_leaf_pair_forces.  A plan is bound to its device, dim and body count; not thread-safe. */
 typedef struct nbx_leaf_plan nbx_leaf_plan;
 int nbx_leaf_plan_create(nbx_leaf_plan** out, int device, int dim, size_t n_bodies,
                          const uint32_t* leaf_offsets, const uint32_t* leaf_bodies, size_t n_leaves,
