@@ -62,3 +62,13 @@ def test_plain_gpus_n_starts_the_ranks_as_a_child_process():
     assert p.returncode != 0
     assert "must be launched with" not in p.stderr
     assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-2000:]
+
+
+def test_cpu_baseline_leg_runs_its_solvers_in_child_processes(reference):
+    """bench.py's cpu_baseline on a small sample: the reference's object code, one fresh process per thread count (OpenMP sizes its
+    pool at start-up), both solvers reported in ordered pairs per second, the --cpu-baseline-n override honoured."""
+    out = bench.cpu_baseline(8192, 3, 1, budget_s=0.05, n_sample=3000)
+    assert out["kind"] == "reference" and out["cores"] >= 1 and out["value"] > 0
+    assert [r["n"] for r in out["all_runs"]][:2] == [3000, 3000]
+    assert {r["solver"] for r in out["all_runs"]} == {"brute_force_omp_n_body_2<3>", "brute_force_omp_n_body_1<3>"}
+    assert "first 3000 bodies" in out["sample"]
